@@ -1,0 +1,159 @@
+"""numpy front-end of the CPU ORACLE (oracle/sdn_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product package scenedreamer_amd never does.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "sdn_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s", "liboracle.so"], check=True,
+                       capture_output=True)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_fast_hash.restype = ctypes.c_uint32
+        _lib.oracle_grid_index.restype = ctypes.c_uint32
+        _lib.oracle_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def num_threads():
+    return int(lib().oracle_num_threads())
+
+
+def camera_frame(cam_dir, cam_up):
+    out = np.empty(9, np.float32)
+    lib().oracle_camera_frame(_p(_f32(cam_dir)), _p(_f32(cam_up)), _p(out))
+    return out[0:3], out[3:6], out[6:9]
+
+
+def rvip(vox, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples, want_steps=False):
+    """Oracle of voxlib.ray_voxel_intersection_perspective.  `vox` may be any-strided int32 ndarray."""
+    assert vox.dtype == np.int32 and vox.ndim == 3
+    H, W, M = int(img_dims[0]), int(img_dims[1]), int(max_samples)
+    dims = np.asarray(vox.shape, np.int64)
+    strides = np.asarray([s // 4 for s in vox.strides], np.int64)
+    out_id = np.empty((H, W, M, 1), np.int32)
+    out_depth = np.empty((2, H, W, M, 1), np.float32)
+    out_dirs = np.empty((H, W, 1, 3), np.float32)
+    steps = np.zeros((H, W), np.int32) if want_steps else None
+    lib().oracle_rvip(ctypes.c_void_p(vox.ctypes.data), _p(dims), _p(strides), _p(_f32(cam_ori)), _p(_f32(cam_dir)),
+                      _p(_f32(cam_up)), ctypes.c_float(float(cam_f)), _p(_f32(cam_c)),
+                      _p(np.asarray([H, W], np.int32)), ctypes.c_int(M), _p(out_id), _p(out_depth), _p(out_dirs),
+                      _p(steps) if want_steps else None)
+    if want_steps:
+        return out_id, out_depth, out_dirs, steps
+    return out_id, out_depth, out_dirs
+
+
+def _pe_shape(x, dim, mult):
+    if dim < 0:
+        dim += x.ndim
+    pre = int(np.prod(x.shape[:dim], dtype=np.int64))
+    post = int(np.prod(x.shape[dim:], dtype=np.int64))
+    shape = list(x.shape)
+    shape[dim] *= mult
+    return pre, post, shape
+
+
+def posenc_fwd(x, ndegrees, dim=-1, incl_orig=False):
+    x = _f32(x)
+    mult = 2 * ndegrees + (1 if incl_orig else 0)
+    pre, post, shape = _pe_shape(x, dim, mult)
+    out = np.empty(shape, np.float32)
+    lib().oracle_posenc_fwd(_p(x), _p(out), ctypes.c_int64(pre), ctypes.c_int64(post), ctypes.c_int(ndegrees),
+                            ctypes.c_int(int(incl_orig)))
+    return out
+
+
+def posenc_bwd(out_grad, out, ndegrees, dim=-1, incl_orig=False):
+    out_grad, out = _f32(out_grad), _f32(out)
+    mult = 2 * ndegrees + (1 if incl_orig else 0)
+    if dim < 0:
+        dim += out.ndim
+    shape = list(out.shape)
+    shape[dim] //= mult
+    pre = int(np.prod(shape[:dim], dtype=np.int64))
+    post = int(np.prod(shape[dim:], dtype=np.int64))
+    ig = np.empty(shape, np.float32)
+    lib().oracle_posenc_bwd(_p(out_grad), _p(out), _p(ig), ctypes.c_int64(pre), ctypes.c_int64(post),
+                            ctypes.c_int(ndegrees), ctypes.c_int(int(incl_orig)))
+    return ig
+
+
+def fast_hash(pos_grid):
+    pg = np.ascontiguousarray(pos_grid, dtype=np.uint32)
+    return int(lib().oracle_fast_hash(_p(pg), ctypes.c_uint32(pg.size)))
+
+
+def grid_index(D, C, gridtype, align_corners, hashmap_size, resolution, pos_grid):
+    pg = np.ascontiguousarray(pos_grid, dtype=np.uint32)
+    return int(lib().oracle_grid_index(ctypes.c_uint32(D), ctypes.c_uint32(C), ctypes.c_uint32(gridtype),
+                                       ctypes.c_int(int(align_corners)), ctypes.c_uint32(hashmap_size),
+                                       ctypes.c_uint32(resolution), _p(pg)))
+
+
+def level_params(level, S, H):
+    scale = ctypes.c_float()
+    res = ctypes.c_uint32()
+    lib().oracle_level_params(ctypes.c_uint32(level), ctypes.c_float(S), ctypes.c_uint32(H), ctypes.byref(scale),
+                              ctypes.byref(res))
+    return scale.value, res.value
+
+
+def grid_encode_fwd(inputs, embeddings, offsets, S, H, calc_grad_inputs=False, gridtype=0, align_corners=False):
+    """Oracle of _gridencoder.grid_encode_forward.  Returns outputs [L,B,C] (and dy_dx [B, L*D*C])."""
+    inputs, embeddings = _f32(inputs), _f32(embeddings)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    B, D = inputs.shape
+    C = embeddings.shape[1]
+    L = offsets.size - 1
+    out = np.empty((L, B, C), np.float32)
+    dy_dx = np.empty((B, L * D * C), np.float32) if calc_grad_inputs else None
+    lib().oracle_grid_encode_fwd(_p(inputs), _p(embeddings), _p(offsets), _p(out), ctypes.c_uint32(B),
+                                 ctypes.c_uint32(D), ctypes.c_uint32(C), ctypes.c_uint32(L), ctypes.c_float(S),
+                                 ctypes.c_uint32(H), ctypes.c_int(int(calc_grad_inputs)),
+                                 _p(dy_dx) if calc_grad_inputs else None, ctypes.c_uint32(gridtype),
+                                 ctypes.c_int(int(align_corners)))
+    return (out, dy_dx) if calc_grad_inputs else out
+
+
+def grid_encode_bwd(grad, inputs, embeddings_shape, offsets, S, H, dy_dx=None, gridtype=0, align_corners=False):
+    """Oracle of _gridencoder.grid_encode_backward (f32).  grad [L,B,C] -> (grad_embeddings, grad_inputs|None)."""
+    grad, inputs = _f32(grad), _f32(inputs)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    L, B, C = grad.shape
+    D = inputs.shape[1]
+    gg = np.zeros(embeddings_shape, np.float32)
+    gi = np.zeros((B, D), np.float32) if dy_dx is not None else None
+    lib().oracle_grid_encode_bwd(_p(grad), _p(inputs), _p(offsets), _p(gg), ctypes.c_uint32(B), ctypes.c_uint32(D),
+                                 ctypes.c_uint32(C), ctypes.c_uint32(L), ctypes.c_float(S), ctypes.c_uint32(H),
+                                 ctypes.c_int(int(dy_dx is not None)), _p(_f32(dy_dx)) if dy_dx is not None else None,
+                                 _p(gi) if gi is not None else None, ctypes.c_uint32(gridtype),
+                                 ctypes.c_int(int(align_corners)))
+    return gg, gi

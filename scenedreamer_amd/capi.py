@@ -1,0 +1,84 @@
+"""ctypes binding of libsdnative.so (the C ABI declared in include/sdnative.h).
+
+The library is REQUIRED: there is no Python/CPU fallback.  If it is missing the
+import of any op raises immediately (build it with `python -m scenedreamer_amd.build`).
+`import torch` happens before the dlopen on purpose: libsdnative.so needs
+libamdhip64.so.7 and must bind to the HIP runtime instance PyTorch already
+loaded, otherwise streams and device pointers would belong to two runtimes.
+"""
+import ctypes
+import os
+import threading
+
+import torch  # noqa: F401  (must be imported before dlopen, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsdnative.so")
+
+SDN_F32, SDN_F16 = 0, 1
+
+_lib = None
+_lock = threading.Lock()
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_u = ctypes.c_uint32
+c_f = ctypes.c_float
+c_i64 = ctypes.c_int64
+
+_SIGNATURES = {
+    "sdn_abi_version": (c_i, []),
+    "sdn_last_error": (ctypes.c_char_p, []),
+    "sdn_rvip": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "sdn_posenc_fwd": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p]),
+    "sdn_posenc_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_p]),
+    "sdn_grid_encode_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_u, c_u, c_u, c_u, c_f, c_u, c_i, c_p, c_u, c_i, c_p]),
+    "sdn_grid_encode_bwd": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_u, c_u, c_u, c_u, c_f, c_u, c_i, c_p, c_p, c_u,
+                                  c_i, c_p]),
+}
+# entry points added by later kernels register themselves here (name -> (restype, argtypes))
+EXTRA_SIGNATURES = {}
+
+
+class SdnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Return the loaded library, loading it on first use.  Raises if absent."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        f"{LIB_PATH} not found: the HIP extension is mandatory (no fallback). "
+                        "Build it with `python -m scenedreamer_amd.build`.")
+                L = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+                sigs = dict(_SIGNATURES)
+                sigs.update(EXTRA_SIGNATURES)
+                for name, (res, args) in sigs.items():
+                    fn = getattr(L, name)  # AttributeError if the symbol is not exported
+                    fn.restype = res
+                    fn.argtypes = args
+                if L.sdn_abi_version() != 1:
+                    raise ImportError("libsdnative ABI version mismatch")
+                _lib = L
+    return _lib
+
+
+def declared_symbols():
+    sigs = dict(_SIGNATURES)
+    sigs.update(EXTRA_SIGNATURES)
+    return sorted(sigs)
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib().sdn_last_error().decode("utf-8", "replace")
+        raise SdnError(msg or f"{what} failed with code {code}")
+
+
+def current_stream(device=None):
+    """hipStream_t of PyTorch's current stream as an integer handle."""
+    return torch.cuda.current_stream(device).cuda_stream

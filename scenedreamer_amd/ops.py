@@ -1,0 +1,179 @@
+"""Tensor-level wrappers over the C ABI.
+
+These functions have exactly the signatures of the reference's pybind modules
+(`voxlib`: imaginaire/model_utils/gancraft/voxlib/voxlib.cpp:25-31;
+`_gridencoder`: gridencoder/src/bindings.cpp:5-8): PyTorch owns every tensor
+(allocation through its caching allocator), work is enqueued on PyTorch's
+current stream, argument violations raise RuntimeError like TORCH_CHECK does.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import capi
+
+_f3 = ctypes.c_float * 3
+_f2 = ctypes.c_float * 2
+_i2 = ctypes.c_int * 2
+_l3 = ctypes.c_int64 * 3
+
+
+def _require(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _host3(t, name):
+    if isinstance(t, torch.Tensor):
+        _require(t.dtype == torch.float32, f"{name} must be float32")
+        _require(t.numel() == 3, f"{name} must have 3 elements")
+        v = t.detach().cpu().reshape(3).tolist()  # like .cpu() in ray_voxel_intersection.cu:275-277
+    else:
+        v = [float(x) for x in np.asarray(t, dtype=np.float32).reshape(3)]
+    return _f3(*v)
+
+
+def _stream(t):
+    return capi.current_stream(t.device)
+
+
+def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples):
+    """voxlib.ray_voxel_intersection_perspective (ray_voxel_intersection.cu:253-325).
+
+    Returns [voxel_id i32[H,W,M,1], depth2 f32[2,H,W,M,1], raydirs f32[H,W,1,3]] on in_voxel's device.
+    """
+    _require(isinstance(in_voxel, torch.Tensor) and in_voxel.is_cuda, "in_voxel must be a CUDA tensor")
+    _require(in_voxel.dtype == torch.int32, "in_voxel must be int32")
+    _require(in_voxel.dim() == 3, "in_voxel must be 3-D")
+    _require(len(img_dims) == 2, "img_dims must have 2 entries")
+    H, W, M = int(img_dims[0]), int(img_dims[1]), int(max_samples)
+    cam_f = float(np.asarray(cam_f, dtype=np.float64).reshape(-1)[0])  # training passes a 1-element array
+    dev = in_voxel.device
+    with torch.cuda.device(dev):
+        voxel_id = torch.empty((H, W, M, 1), dtype=torch.int32, device=dev)
+        depth2 = torch.empty((2, H, W, M, 1), dtype=torch.float32, device=dev)
+        raydirs = torch.empty((H, W, 1, 3), dtype=torch.float32, device=dev)
+        if H * W * M == 0:
+            return [voxel_id, depth2, raydirs]
+        rc = capi.lib().sdn_rvip(
+            in_voxel.data_ptr(), _l3(*in_voxel.shape), _l3(*in_voxel.stride()),
+            _host3(cam_ori, "cam_ori"), _host3(cam_dir, "cam_dir"), _host3(cam_up, "cam_up"),
+            cam_f, _f2(float(cam_c[0]), float(cam_c[1])), _i2(H, W), M,
+            voxel_id.data_ptr(), depth2.data_ptr(), raydirs.data_ptr(), _stream(in_voxel))
+    capi.check(rc, "sdn_rvip")
+    return [voxel_id, depth2, raydirs]
+
+
+def _pe_sizes(t, dim):
+    if dim < 0:
+        dim = t.dim() + dim
+    _require(0 <= dim < t.dim(), "dim out of range")
+    pre = 1
+    for i in range(dim):
+        pre *= t.size(i)
+    post = 1
+    for i in range(dim, t.dim()):
+        post *= t.size(i)
+    return dim, pre, post
+
+
+def positional_encoding(in_feature, ndegrees, dim, incl_orig):
+    """voxlib.positional_encoding (positional_encoding_kernel.cu:129-197)."""
+    _require(isinstance(in_feature, torch.Tensor) and in_feature.is_cuda, "in_feature must be a CUDA tensor")
+    _require(in_feature.dtype == torch.float32, "in_feature must be float32")
+    _require(in_feature.is_contiguous(), "in_feature must be contiguous")
+    dim, pre, post = _pe_sizes(in_feature, dim)
+    mult = ndegrees * 2 + (1 if incl_orig else 0)
+    shape = list(in_feature.shape)
+    shape[dim] *= mult
+    with torch.cuda.device(in_feature.device):
+        out = torch.empty(shape, dtype=torch.float32, device=in_feature.device)
+        rc = capi.lib().sdn_posenc_fwd(in_feature.data_ptr(), out.data_ptr(), pre, post, int(ndegrees),
+                                       int(bool(incl_orig)), _stream(in_feature))
+    capi.check(rc, "sdn_posenc_fwd")
+    return out
+
+
+def positional_encoding_backward(out_feature_grad, out_feature, ndegrees, dim, incl_orig):
+    """voxlib.positional_encoding_backward (positional_encoding_kernel.cu:209-285)."""
+    _require(out_feature_grad.is_cuda and out_feature.is_cuda, "out_feature_grad must be a CUDA tensor")
+    _require(out_feature_grad.dtype == torch.float32 and out_feature.dtype == torch.float32, "float32 expected")
+    _require(out_feature.is_contiguous(), "out_feature must be contiguous")
+    out_feature_grad = out_feature_grad.contiguous()
+    mult = ndegrees * 2 + (1 if incl_orig else 0)
+    if dim < 0:
+        dim = out_feature.dim() + dim
+    shape = list(out_feature.shape)
+    _require(shape[dim] % mult == 0, "encoded dim is not a multiple of 2*ndegrees(+1)")
+    shape[dim] //= mult
+    pre = 1
+    for i in range(dim):
+        pre *= shape[i]
+    post = 1
+    for i in range(dim, len(shape)):
+        post *= shape[i]
+    with torch.cuda.device(out_feature.device):
+        in_grad = torch.empty(shape, dtype=torch.float32, device=out_feature.device)
+        rc = capi.lib().sdn_posenc_bwd(out_feature_grad.data_ptr(), out_feature.data_ptr(), in_grad.data_ptr(), pre,
+                                       post, int(ndegrees), int(bool(incl_orig)), _stream(out_feature))
+    capi.check(rc, "sdn_posenc_bwd")
+    return in_grad
+
+
+def sp_trilinear_worldcoord(*args, **kwargs):
+    raise NotImplementedError("sp_trilinear_worldcoord is GANcraft-only and off SceneDreamer's path "
+                              "(scenedreamer.py:285 overrides its only caller)")
+
+
+def sp_trilinear_worldcoord_backward(*args, **kwargs):
+    raise NotImplementedError("sp_trilinear_worldcoord_backward is GANcraft-only and off SceneDreamer's path")
+
+
+def _dtype_code(t, name):
+    if t.dtype == torch.float32:
+        return capi.SDN_F32
+    if t.dtype == torch.float16:
+        return capi.SDN_F16
+    raise RuntimeError(f"{name} must be a float32 or float16 tensor")
+
+
+def _check_dev(t, name, contiguous=True):
+    _require(isinstance(t, torch.Tensor) and t.is_cuda, f"{name} must be a CUDA tensor")
+    if contiguous:
+        _require(t.is_contiguous(), f"{name} must be a contiguous tensor")
+
+
+def grid_encode_forward(inputs, embeddings, offsets, outputs, B, D, C, L, S, H, calc_grad_inputs, dy_dx, gridtype,
+                        align_corners):
+    """_gridencoder.grid_encode_forward (gridencoder.cu:423-446): writes `outputs` [L,B,C] in place."""
+    for t, n in ((inputs, "inputs"), (embeddings, "embeddings"), (offsets, "offsets"), (outputs, "outputs"),
+                 (dy_dx, "dy_dx")):
+        _check_dev(t, n)
+    _require(inputs.dtype == torch.float32, "inputs must be a float32 tensor")
+    _require(offsets.dtype == torch.int32, "offsets must be an int tensor")
+    code = _dtype_code(embeddings, "embeddings")
+    _require(outputs.dtype == embeddings.dtype and dy_dx.dtype == embeddings.dtype,
+             "outputs/dy_dx must have the dtype of embeddings")
+    with torch.cuda.device(inputs.device):
+        rc = capi.lib().sdn_grid_encode_fwd(inputs.data_ptr(), embeddings.data_ptr(), code, offsets.data_ptr(),
+                                            outputs.data_ptr(), int(B), int(D), int(C), int(L), float(S), int(H),
+                                            int(bool(calc_grad_inputs)), dy_dx.data_ptr(), int(gridtype),
+                                            int(bool(align_corners)), _stream(inputs))
+    capi.check(rc, "sdn_grid_encode_fwd")
+
+
+def grid_encode_backward(grad, inputs, embeddings, offsets, grad_embeddings, B, D, C, L, S, H, calc_grad_inputs, dy_dx,
+                         grad_inputs, gridtype, align_corners):
+    """_gridencoder.grid_encode_backward (gridencoder.cu:448-478): accumulates into `grad_embeddings`."""
+    for t, n in ((grad, "grad"), (inputs, "inputs"), (embeddings, "embeddings"), (offsets, "offsets"),
+                 (grad_embeddings, "grad_embeddings"), (dy_dx, "dy_dx"), (grad_inputs, "grad_inputs")):
+        _check_dev(t, n)
+    code = _dtype_code(grad, "grad")
+    with torch.cuda.device(inputs.device):
+        rc = capi.lib().sdn_grid_encode_bwd(grad.data_ptr(), inputs.data_ptr(), embeddings.data_ptr(), code,
+                                            offsets.data_ptr(), grad_embeddings.data_ptr(), int(B), int(D), int(C),
+                                            int(L), float(S), int(H), int(bool(calc_grad_inputs)), dy_dx.data_ptr(),
+                                            grad_inputs.data_ptr(), int(gridtype), int(bool(align_corners)),
+                                            _stream(inputs))
+    capi.check(rc, "sdn_grid_encode_bwd")
