@@ -64,6 +64,14 @@ __device__ __forceinline__ void level_params(const GridLevels &lv, uint32_t leve
     }
 }
 
+// a * b + c with two roundings (no FMA contraction), whatever the translation unit's -ffp-contract:
+// HIP's __fmul_rn/__fadd_rn are plain `*` / `+` and still get fused.
+__device__ __forceinline__ float mul_add_exact(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float p = a * b;
+    return p + c;
+}
+
 template <uint32_t D>
 __device__ __forceinline__ uint32_t fast_hash(const uint32_t (&pg)[D]) {
     constexpr uint32_t primes[7] = {1u, 2654435761u, 805459861u, 3674653429u, 2097192037u, 1434869437u, 2165219737u};
@@ -213,7 +221,10 @@ __global__ __launch_bounds__(FWD_THREADS) void grid_fwd_kernel(const float *__re
     uint32_t pg[D];
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {  // :133-138
-        pos[d] = x[d] * scale + (align_corners ? 0.0f : 0.5f);
+        // un-contracted multiply-add: the cell index and the fractional position are then
+        // bit-identical to the oracle (an FMA here moves pos by up to 1 ulp = 1.2e-4 at scale 2047,
+        // which shows up as ~6e-5 in the blended feature)
+        pos[d] = mul_add_exact(x[d], scale, align_corners ? 0.0f : 0.5f);
         const float fl = floorf(pos[d]);
         pg[d] = (uint32_t)fl;
         pos[d] -= (float)pg[d];
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const float *__restrict__
     uint32_t pg[D];
 #pragma unroll
     for (uint32_t d = 0; d < D; d++) {
-        pos[d] = x[d] * scale + (align_corners ? 0.0f : 0.5f);
+        pos[d] = mul_add_exact(x[d], scale, align_corners ? 0.0f : 0.5f);
         pg[d] = (uint32_t)floorf(pos[d]);
         pos[d] -= (float)pg[d];
     }
