@@ -1,0 +1,105 @@
+"""Multi-GPU layer: one process per GPU, frames of a camera trajectory sharded across ranks.
+
+The path shards by independent units (frames are pure functions of broadcast-once state and a
+host-computed pose), so there is NO data-path collective: RCCL (torch.distributed
+backend "nccl" on ROCm) is only used once, before rendering, to broadcast the scene volume, the
+weights and the style code from rank 0.  Large tensors are sent as scatter + all_gather so that the
+root pushes a distinct 1/N slice over each of its xGMI links instead of N-1 full copies (xGMI is
+point-to-point; a flat broadcast is root-egress bound).  Works with the gloo backend on CPU tensors,
+which is how the logic is tested without GPUs.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_frames(frames, rank, world):
+    """Round-robin frame assignment: frame f is rendered by rank f % world."""
+    return list(frames)[rank::world]
+
+
+def _is_init():
+    return dist.is_available() and dist.is_initialized()
+
+
+def broadcast_large(t, src=0, min_numel=1 << 20):
+    """Broadcast tensor `t` (allocated with the right shape/dtype on every rank) from `src`."""
+    world = dist.get_world_size()
+    if world == 1:
+        return t
+    flat = t.reshape(-1)
+    n = flat.numel()
+    if n < min_numel or n % world != 0 or not t.is_contiguous():
+        dist.broadcast(t, src)
+        return t
+    chunk = n // world
+    rank = dist.get_rank()
+    mine = torch.empty(chunk, dtype=t.dtype, device=t.device)
+    parts = [flat[i * chunk:(i + 1) * chunk].contiguous() for i in range(world)] if rank == src else None
+    dist.scatter(mine, parts, src=src)
+    outs = [torch.empty(chunk, dtype=t.dtype, device=t.device) for _ in range(world)]
+    dist.all_gather(outs, mine)
+    if rank != src:
+        for i, o in enumerate(outs):
+            flat[i * chunk:(i + 1) * chunk].copy_(o)
+    return t
+
+
+def checksum(t):
+    """Order-independent 64-bit checksum of a tensor's bytes (integer sum of 32-bit words)."""
+    b = t.contiguous().reshape(-1)
+    if b.element_size() == 4:
+        v = b.view(torch.int32)
+    elif b.element_size() == 8:
+        v = b.view(torch.int64)
+    else:
+        v = b.view(torch.uint8)
+    return int(v.to(torch.int64).sum().item())
+
+
+def broadcast_tensor_dict(d, dev, src=0, verify=True):
+    """Broadcast a name -> tensor dict known only on `src`.  Returns the dict on every rank."""
+    rank = dist.get_rank()
+    meta = [None]
+    if rank == src:
+        meta[0] = [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in d.items()]
+    dist.broadcast_object_list(meta, src=src)
+    out = {}
+    for k, shape, dt in meta[0]:
+        dtype = getattr(torch, dt)
+        t = d[k].to(dev).contiguous() if rank == src else torch.empty(shape, dtype=dtype, device=dev)
+        broadcast_large(t, src)
+        out[k] = t
+    if verify:
+        sums = torch.tensor([checksum(v) for v in out.values()], dtype=torch.int64, device=dev)
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise RuntimeError("broadcast integrity check failed: checksums differ across ranks")
+    return out
+
+
+def broadcast_state(scene, weights, style, dev, src=0):
+    """Rank `src` holds (scene, weights dict of ndarrays, style); everyone gets equivalent objects on `dev`."""
+    from .synth import Scene
+    rank = dist.get_rank()
+    tensors = {}
+    if rank == src:
+        tensors.update({"w:" + k: torch.as_tensor(np.asarray(v)) for k, v in weights.items()})
+        tensors["s:voxel_t"] = scene.voxel_t
+        tensors["s:heightmap"] = scene.heightmap.to(torch.int64)
+        tensors["s:current_height_map"] = scene.current_height_map
+        tensors["s:current_semantic_map"] = scene.current_semantic_map
+        tensors["s:trans_mat"] = scene.trans_mat
+        tensors["z:style"] = torch.as_tensor(np.asarray(style))
+    got = broadcast_tensor_dict(tensors, dev, src)
+    sc = Scene()
+    sc.voxel_t = got["s:voxel_t"]
+    sc.heightmap = got["s:heightmap"].cpu()
+    sc.current_height_map = got["s:current_height_map"]
+    sc.current_semantic_map = got["s:current_semantic_map"]
+    sc.trans_mat = got["s:trans_mat"].cpu()
+    sc.sample_size = int(sc.voxel_t.shape[1])
+    w = {k[2:]: v for k, v in got.items() if k.startswith("w:")}
+    return sc, w, got["z:style"].cpu().numpy()

@@ -1,0 +1,310 @@
+"""Frame renderer: the host-side mirror of Generator.inference_givenstyle's per-frame body
+(imaginaire/generators/scenedreamer.py:573-628) on top of libsdnative.
+
+Two interchangeable per-pixel paths produce net_out [1, Hp, Wp, 64] for the padded frame:
+
+  * "unfused": the reference's op sequence -- voxlib.ray_voxel_intersection_perspective ->
+    sample placement -> GridEncoder.forward -> render MLP -> volume rendering -- with the three
+    native ops served by the drop-in HIP kernels and everything else by PyTorch ops on the GPU
+    (exactly what the unmodified reference generator does when our shim modules are installed);
+  * "fused": sample placement, hash-grid lookup, MLP and compositing inside libsdnative's field
+    kernels (see csrc/field.hip), selected with mode="fused".
+
+Differences from the reference's loop that do not change the result: every ray is evaluated once on
+the full padded frame instead of in 40 overlapping 158-px tiles (the per-pixel field has no spatial
+coupling), and the render CNN runs once on the padded frame and is cropped by pad/2 afterwards (its
+receptive radius of 4 px is smaller than the 15-px crop, gancraft_base.py:180-190).  Per-style
+constants (W * alpha, beta of every ModLinear; the label-bias table replacing the one-hot matmul)
+are folded once per style code instead of once per tile.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+from .camera import frame_intrinsics
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def load_label_lut():
+    """minecraft block id -> reduced label (12 classes), mc_lbl_reduction.py:36-43 (data file)."""
+    return json.load(open(os.path.join(_DATA, "mc2reduced.json")))
+
+
+def _lrelu(x):
+    return F.leaky_relu(x, 0.2)
+
+
+class Renderer:
+    def __init__(self, weights, scene, device="cuda", num_blocks_early_stop=6, sample_depth=3.0, dists_scale=0.25,
+                 pad=30):
+        self.dev = torch.device(device)
+        self.w = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))).to(self.dev)
+                  for k, v in weights.items()}
+        lut = load_label_lut()
+        t = torch.tensor(lut["lut"], dtype=torch.long)
+        t[t == lut["ignore_id"]] = lut["dirt_id"]  # mc2reduced(ign2dirt=True), mc_utils.py:241-246
+        self.lut = t.to(self.dev)
+        self.M = num_blocks_early_stop
+        self.sample_depth = float(sample_depth)
+        self.dists_scale = float(dists_scale)
+        self.pad = pad
+        offs = self.w["hash_encoder.offsets"]
+        self.grid_L = offs.numel() - 1
+        self.grid_S = float(np.log2(np.exp2(np.log2(2048 / 16) / (self.grid_L - 1))))
+        self.timings = {}
+        self.set_scene(scene)
+
+    # ------------------------------------------------------------------ once per scene / style
+    def set_scene(self, scene):
+        self.scene = scene
+        self.voxel_t = scene.voxel_t.to(self.dev)
+        w = self.w
+        with torch.no_grad():  # ConditionalHashGrid.forward, layers.py:40-55
+            h = _lrelu(F.conv2d(scene.current_height_map.to(self.dev), w["world_encoder.hconv_head.weight"],
+                                w["world_encoder.hconv_head.bias"], stride=2, padding=1))
+            s = _lrelu(F.conv2d(scene.current_semantic_map.to(self.dev), w["world_encoder.sconv_head.weight"],
+                                w["world_encoder.sconv_head.bias"], stride=2, padding=1))
+            x = torch.cat([h, s], dim=1)
+            for i in range(5):
+                x = F.relu(F.conv2d(x, w[f"world_encoder.conv_blocks.{i}.layers.0.weight"], None, stride=1, padding=1))
+                x = F.relu(F.conv2d(x, w[f"world_encoder.conv_blocks.{i}.layers.2.weight"], None, stride=2, padding=1))
+                x = _lrelu(x)
+            x = x.permute(0, 2, 3, 1)
+            x = x.reshape(x.shape[0], -1, x.shape[-1]).mean(dim=1)
+            x = _lrelu(F.linear(x, w["world_encoder.fc1.weight"], w["world_encoder.fc1.bias"]))
+            self.global_enc = torch.tanh(F.linear(x, w["world_encoder.fc2.weight"], w["world_encoder.fc2.bias"]))
+        self._fused_scene = None
+
+    def set_style(self, style):
+        w = self.w
+        with torch.no_grad():
+            z = F.normalize(torch.as_tensor(style, dtype=torch.float32, device=self.dev), p=2, dim=-1)
+            for i in range(5):  # StyleMLP.forward, gancraft_base.py:113-126
+                z = _lrelu(F.linear(z, w[f"style_net.fc_layers.{i}.weight"], w[f"style_net.fc_layers.{i}.bias"]))
+            z = _lrelu(F.linear(z, w["style_net.fc_out.weight"], w["style_net.fc_out.bias"]))
+        self.set_style_code(z)
+
+    def set_style_code(self, z):
+        """Fold an intermediate style code z [1,256] (= style_net(style)) into per-style constants."""
+        w = self.w
+        with torch.no_grad():
+            z = torch.as_tensor(z, dtype=torch.float32, device=self.dev).reshape(1, -1)
+            self.z = z
+            # ModLinear with N=1: W' = W * alpha (per input channel), beta per output (layers.py:247-269)
+            self.mod = {}
+            for i in (2, 3, 4, 5, 6):
+                n = f"render_net.fc_{i}"
+                alpha = F.linear(z, w[n + ".weight_alpha"], w[n + ".bias_alpha"])       # [1, in]
+                beta = F.linear(z, w[n + ".weight_beta"], w[n + ".bias_beta"])          # [1, out]
+                self.mod[i] = ((w[n + ".weight"] * alpha).contiguous(), beta[0].contiguous())
+            # one-hot(label) @ fc_m_a^T + fc_1.bias  ==  row lookup in a [12, 256] table
+            self.label_bias = (w["render_net.fc_m_a.weight"].t() + w["render_net.fc_1.bias"][None, :]).contiguous()
+            self.sky_z = F.linear(z, w["sky_net.fc_z_a.weight"])                         # [1, 256]
+            self.cnn_adapt = F.linear(z, w["denoiser.fc_z_cond.weight"], w["denoiser.fc_z_cond.bias"])
+        self._fused_style = None
+
+    # ------------------------------------------------------------------ stages
+    def cast_rays(self, pose, resolution_hw):
+        cam_ori, cam_dir, cam_up, cam_f = pose
+        f, c, cam_res = frame_intrinsics(cam_f, resolution_hw, self.pad)
+        vid, d2, rd = ops.ray_voxel_intersection_perspective(self.voxel_t, cam_ori, cam_dir, cam_up, f, c, cam_res,
+                                                             self.M)
+        return vid, d2, rd, cam_res
+
+    def sky_features(self, raydirs):
+        """sky_net(PE(raydirs)) for every ray: [R,3] -> [R,64] (scenedreamer.py:368-370, gancraft_base.py:150-169)."""
+        w = self.w
+        pe = ops.positional_encoding(raydirs.contiguous(), 5, -1, True)
+        y = _lrelu(F.linear(pe, w["sky_net.fc1.weight"], w["sky_net.fc1.bias"]) + self.sky_z)
+        for i in (2, 3, 4, 5):
+            y = _lrelu(F.linear(y, w[f"sky_net.fc{i}.weight"], w[f"sky_net.fc{i}.bias"]))
+        return F.linear(y, w["sky_net.fc_out_c.weight"], w["sky_net.fc_out_c.bias"])
+
+    def place_samples(self, depth2, ns):
+        """sample_depth_batched, deterministic, no box boundaries (mc_utils.py:82-151).
+        depth2 [2,R,M] -> depth [R,ns], dists [R,ns], box index [R,ns]."""
+        t, t2 = depth2[0], depth2[1]
+        d = t2 - t
+        d = torch.where(torch.isnan(d), torch.zeros_like(d), d)
+        accu = torch.cumsum(d, dim=-1)
+        total = accu[:, -1:].clamp(max=self.sample_depth)
+        lin = torch.linspace(0, 1, ns + 3)[1:-1].to(self.dev)   # nsamples = ns+1 stratified points
+        s = lin[None, :] * total
+        mid = (s[:, 1:] + s[:, :-1]) / 2
+        nd = s[:, 1:] - s[:, :-1]
+        idx = (mid[:, None, :] > accu[:, :, None]).sum(dim=1)
+        gaps = torch.cumsum(t[:, 1:] - t2[:, :-1], dim=-1)
+        heads = torch.cat([t[:, :1], gaps + t[:, :1]], dim=-1)
+        depth = torch.gather(heads, 1, idx) + mid
+        return depth, nd, idx
+
+    def field_unfused(self, voxel_id, depth2, raydirs, cam_ori, sky_c, sky_avg, ns):
+        """Per-ray feature net_out [R,64] from [R,M] intersections (scenedreamer.py:313-430)."""
+        w = self.w
+        depth, nd, idx = self.place_samples(depth2, ns)
+        depth = torch.where(torch.isnan(depth) | torch.isinf(depth), torch.zeros_like(depth), depth)
+        wc = raydirs[:, None, :] * depth[:, :, None] + cam_ori[None, None, :]
+        lab = torch.gather(self.lut[voxel_id.long()], 1, idx)
+        delim = torch.tensor([float(v) for v in self.voxel_t.shape], device=self.dev)
+        n = wc / delim * 2 - 1
+        x5 = torch.cat([n, self.global_enc[:, None, :].expand(n.shape[0], n.shape[1], 2)], dim=-1)
+        x5 = ((x5 + 1) / 2).reshape(-1, 5).contiguous()           # GridEncoder.forward, grid.py:144
+        B = x5.shape[0]
+        feats = torch.empty(self.grid_L, B, 8, device=self.dev)
+        ops.grid_encode_forward(x5, w["hash_encoder.embeddings"], w["hash_encoder.offsets"], feats, B, 5, 8,
+                                self.grid_L, self.grid_S, 16, False, torch.empty(1, device=self.dev), 0, False)
+        feats = feats.permute(1, 0, 2).reshape(B, self.grid_L * 8)
+        f = _lrelu(F.linear(feats, w["render_net.fc_1.weight"]) + self.label_bias[lab.reshape(-1)])
+        for i in (2, 3, 4):
+            f = _lrelu(torch.addmm(self.mod[i][1], f, self.mod[i][0].t()))
+        sigma = F.linear(f, w["render_net.fc_sigma.weight"], w["render_net.fc_sigma.bias"]).reshape(-1, ns)
+        for i in (5, 6):
+            f = _lrelu(torch.addmm(self.mod[i][1], f, self.mod[i][0].t()))
+        color = F.linear(f, w["render_net.fc_out_c.weight"], w["render_net.fc_out_c.bias"]).reshape(-1, ns, 64)
+        # volum_rendering_relu (mc_utils.py:154-161) + compositing (scenedreamer.py:373-413)
+        fe = F.relu(sigma) * (nd * self.dists_scale)
+        # exclusive cumsum as roll(cumsum) with a zero head (mc_utils.py:75-79)
+        excl = torch.cat([torch.zeros_like(fe[:, :1]), torch.cumsum(fe, dim=-1)[:, :-1]], dim=-1)
+        wts = (1 - torch.exp(-fe)) * torch.exp(-excl)
+        sky_only = voxel_id[:, :1] == 0
+        wts = wts * (~sky_only).float()
+        T = wts.sum(dim=-1, keepdim=True)
+        is_gnd = (wc[:, :, 0] <= 1.0).any(dim=-1, keepdim=True)
+        nosky = ((voxel_id[:, -1:] != 0) | is_gnd).float()
+        sky = sky_c * (1.0 - nosky) + sky_avg * nosky
+        rgb = torch.clamp(color, -1, 1) + 1
+        rgb_sky = torch.clamp(sky, -1, 1) + 1
+        return (wts[:, :, None] * rgb).sum(dim=1) + (1.0 - T) * rgb_sky - 1
+
+    def render_cnn(self, net_out):
+        """_forward_global + RenderCNN (gancraft_base.py:588-603, :202-225): [1,Hp,Wp,64] -> [1,3,Hp,Wp]."""
+        w = self.w
+        a = torch.chunk(self.cnn_adapt, 4, dim=-1)
+        mod = lambda v, s, b: v * (s[..., None, None] + 1) + b[..., None, None]
+        cv = lambda v, n, p: F.conv2d(v, w[f"denoiser.{n}.weight"], w.get(f"denoiser.{n}.bias"), padding=p)
+        x = net_out.permute(0, 3, 1, 2).contiguous()
+        y = _lrelu(cv(x, "conv1", 0))
+        y = y + cv(_lrelu(cv(y, "conv2a", 1)), "conv2b", 1)
+        y = _lrelu(mod(y, a[0], a[1]))
+        y = y + cv(_lrelu(cv(y, "conv3a", 1)), "conv3b", 1)
+        y = _lrelu(mod(y, a[2], a[3]))
+        y = y + cv(_lrelu(cv(y, "conv4a", 0)), "conv4b", 0)
+        y = _lrelu(y)
+        return torch.tanh(cv(y, "conv4", 0))
+
+    # ------------------------------------------------------------------ measurement
+    def compute_dtype(self, mode):
+        return "f32" if mode == "unfused" else "f32 (hash grid) + f16x3-split MFMA with f32 accumulate (MLP)"
+
+    def measure_roofline(self, pose, resolution_hw, num_samples, mode, hbm_peak_gbps=8000.0):
+        """Achieved effective gather bandwidth of the grid-sample kernel, timed with events on the launch
+        stream (PyTorch's current stream).  Algorithmic bytes per sample: SURVEY.md 8(d)."""
+        with torch.no_grad():
+            vid, d2, rd, cam_res = self.cast_rays(pose, resolution_hw)
+            R = cam_res[0] * cam_res[1]
+            cam_ori = torch.as_tensor(pose[0], dtype=torch.float32).to(self.dev)
+            if mode == "unfused":
+                n = min(R, 1 << 16)
+                depth, _, _ = self.place_samples(d2.view(2, R, self.M)[:, :n], num_samples)
+                depth = torch.nan_to_num(depth, nan=0.0, posinf=0.0, neginf=0.0)
+                wc = rd.view(R, 3)[:n, None, :] * depth[:, :, None] + cam_ori
+                delim = torch.tensor([float(v) for v in self.voxel_t.shape], device=self.dev)
+                x5 = torch.cat([wc / delim * 2 - 1, self.global_enc[:, None, :].expand(n, num_samples, 2)], dim=-1)
+                x5 = ((x5 + 1) / 2).reshape(-1, 5).contiguous()
+                B = x5.shape[0]
+                feats = torch.empty(self.grid_L, B, 8, device=self.dev)
+                dummy = torch.empty(1, device=self.dev)
+                w = self.w
+                ms = _time_ms(lambda: ops.grid_encode_forward(x5, w["hash_encoder.embeddings"], w["hash_encoder.offsets"],
+                                                              feats, B, 5, 8, self.grid_L, self.grid_S, 16, False, dummy,
+                                                              0, False))
+                per_sample, kernel = 16916, "grid_fwd_kernel<float,5,8>"
+            else:
+                from . import fused
+                B, ms, per_sample, kernel = fused.time_encode_kernel(self, vid, d2, rd, cam_ori, num_samples)
+        achieved = B * per_sample / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": hbm_peak_gbps, "unit": "GB/s",
+                "frac": achieved / hbm_peak_gbps, "traffic": None, "samples_per_launch": B,
+                "algorithmic_bytes_per_sample": per_sample, "avg_launch_ms": ms}
+
+    # ------------------------------------------------------------------ frame
+    def render_frame(self, pose, resolution_hw=(540, 960), num_samples=24, mode="unfused", cnn=True,
+                     ray_chunk=1 << 16, timers=None):
+        """One frame of the trajectory.  Returns image [1,3,H,W] (or net_out [1,Hp,Wp,64] if cnn=False)."""
+        ev = _Stamps(timers)
+        with torch.no_grad():
+            ev.mark("start")
+            vid, d2, rd, cam_res = self.cast_rays(pose, resolution_hw)
+            ev.mark("rvip")
+            Hp, Wp = cam_res
+            R = Hp * Wp
+            vid = vid.view(R, self.M)
+            d2 = d2.view(2, R, self.M)
+            rd = rd.view(R, 3)
+            cam_ori = torch.as_tensor(pose[0], dtype=torch.float32).to(self.dev)
+            sky_c = self.sky_features(rd)
+            sky_avg = sky_c.mean(dim=0, keepdim=True)        # full-frame mean, scenedreamer.py:592-598
+            ev.mark("sky")
+            if mode == "unfused":
+                outs = []
+                for r0 in range(0, R, ray_chunk):
+                    r1 = min(r0 + ray_chunk, R)
+                    outs.append(self.field_unfused(vid[r0:r1], d2[:, r0:r1], rd[r0:r1], cam_ori, sky_c[r0:r1],
+                                                   sky_avg, num_samples))
+                net_out = torch.cat(outs, dim=0)
+            elif mode == "fused":
+                from . import fused
+                net_out = fused.field_fused(self, vid, d2, rd, cam_ori, sky_c, sky_avg, num_samples)
+            else:
+                raise ValueError(mode)
+            net_out = net_out.view(1, Hp, Wp, 64)
+            ev.mark("field")
+            if not cnn:
+                ev.done()
+                return net_out
+            img = self.render_cnn(net_out)
+            p = self.pad // 2
+            if self.pad:
+                img = img[:, :, p:-p, p:-p]
+            ev.mark("cnn")
+            ev.done()
+            return img
+
+
+def _time_ms(fn, reps=5):
+    fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+
+class _Stamps:
+    """Optional per-stage GPU timing with events on the current stream."""
+
+    def __init__(self, sink):
+        self.sink = sink
+        self.ev = []
+
+    def mark(self, name):
+        if self.sink is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.ev.append((name, e))
+
+    def done(self):
+        if self.sink is not None and self.ev:
+            torch.cuda.synchronize()
+            for (n0, e0), (n1, e1) in zip(self.ev[:-1], self.ev[1:]):
+                self.sink.setdefault(n1, []).append(e0.elapsed_time(e1))
