@@ -20,6 +20,7 @@
 #ifndef SDNATIVE_H
 #define SDNATIVE_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -88,12 +89,60 @@ int sdn_grid_encode_fwd(const float *inputs, const void *embeddings, int emb_dty
                         void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                         int calc_grad_inputs, void *dy_dx, uint32_t gridtype, int align_corners,
                         sdn_stream_t stream);
+/*   per-level scale = exp2f(l*S)*H-1 and resolution = ceil(scale)+1 exactly as every kernel of this library
+ *   uses them (gridencoder.cu:126-127), evaluated on the host; resolutions_host may be NULL              */
+int sdn_grid_level_scales(uint32_t L, float S, uint32_t H, float *scales_host, uint32_t *resolutions_host);
 /*   grad [L,B,C]; grad_embeddings [sO,C] pre-zeroed by the caller (accumulated with atomics);
  *   grad_inputs [B,D] written when calc_grad_inputs.  F32 only in this release.          */
 int sdn_grid_encode_bwd(const void *grad, const float *inputs, const void *embeddings, int emb_dtype,
                         const int32_t *offsets, void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void *dy_dx,
                         void *grad_inputs, uint32_t gridtype, int align_corners, sdn_stream_t stream);
+
+
+/* ---------------------------------------------------------------------------
+ * Fused field renderer: fast path for Generator._forward_perpix / _forward_perpix_sub
+ * (imaginaire/generators/scenedreamer.py:285-430) = mc_utils.sample_depth_batched (:82-151) +
+ * label lookup (scenedreamer.py:357-363) + GridEncoder.forward (gridencoder/grid.py:140-156) +
+ * LightningMLP.forward (imaginaire/model_utils/layers.py:92-126) + volum_rendering_relu
+ * (mc_utils.py:154-161) + sky compositing (scenedreamer.py:373-413), inference settings
+ * (deterministic sampling, keep_sky_out_avgpool, clip_feat_map=True, N=1).
+ * Only the SceneDreamer grid (D=5, C=8, 16 hashed power-of-two levels) is supported here; anything else
+ * returns SDN_ERR_UNSUPPORTED and callers use the three drop-in ops above.
+ *
+ * Call order: collapse_table once per scene (global_enc), pack_weights once per style code, then per
+ * frame encode -> mlp.  All scratch buffers are caller-allocated (sizes from the *_bytes/_elems helpers).
+ */
+size_t sdn_field_packed_weight_bytes(void);
+size_t sdn_field_consts_floats(void);
+/* float offset of a block inside `consts`: 0 label_bias[12][256] (= fc_m_a^T + fc_1.bias), 1 beta[5][256],
+ * 2 w_sigma[256], 3 b_c[64], 4 b_sigma[1], 5 sky_avg[64] (updated by the caller every frame) */
+int sdn_field_const_offset(int which);
+size_t sdn_field_feat_bytes(int32_t n_rays, int32_t num_samples);
+size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples);
+
+/* embeddings dev f32 [sO,8]; offsets_host int32[L+1]; genc_host f32[2] = world_encoder output;
+ * table3 dev f32 [16, T, 8] (T = rows per level) */
+int sdn_field_collapse_table(const float *embeddings, const int32_t *offsets_host, uint32_t L, float S, uint32_t H,
+                             const float *genc_host, float *table3, sdn_stream_t stream);
+/* w1 dev [256,128] fc_1.weight; wh5_host: host array of 5 dev pointers [256,256] = fc_2..fc_6 weight * alpha;
+ * wc dev [64,256] fc_out_c.weight; packed dev, sdn_field_packed_weight_bytes() bytes */
+int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const float *wc, void *packed,
+                           sdn_stream_t stream);
+/* voxel_id dev i32 [R,M]; depth2 dev f32 [2,R,M]; raydirs dev f32 [R,3]; lut1024 dev u8 [1024] block id ->
+ * reduced label (ignore already mapped to dirt); scales_dev f32 [16]; lin_dev f32 [num_samples+1] =
+ * linspace(0,1,num_samples+3)[1:-1]; outputs: feat, dist, label (aux_elems each), rayflag u8 [R] */
+int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
+                     const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
+                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, int32_t n_rays,
+                     int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
+                     float *dist, uint8_t *label, uint8_t *rayflag, sdn_stream_t stream);
+/* sky_c dev f32 [R,64] = sky_net output per ray; net_out dev f32 [R,64]; n_workgroups <= 0 -> one per CU */
+int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
+                  const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
+                  int32_t n_workgroups, sdn_stream_t stream);
+/* test hook: C[32,32] = A[32,16] * B[16,32] through the MFMA operand layouts field.hip relies on */
+int sdn_debug_mfma_probe(const float *A, const float *B, float *C, sdn_stream_t stream);
 
 #ifdef __cplusplus
 }

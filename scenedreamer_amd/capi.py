@@ -35,6 +35,19 @@ _SIGNATURES = {
     "sdn_grid_encode_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_u, c_u, c_u, c_u, c_f, c_u, c_i, c_p, c_u, c_i, c_p]),
     "sdn_grid_encode_bwd": (c_i, [c_p, c_p, c_p, c_i, c_p, c_p, c_u, c_u, c_u, c_u, c_f, c_u, c_i, c_p, c_p, c_u,
                                   c_i, c_p]),
+    "sdn_grid_level_scales": (c_i, [c_u, c_f, c_u, c_p, c_p]),
+    "sdn_field_packed_weight_bytes": (ctypes.c_size_t, []),
+    "sdn_field_consts_floats": (ctypes.c_size_t, []),
+    "sdn_field_const_offset": (c_i, [c_i]),
+    "sdn_field_feat_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "sdn_field_aux_elems": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "sdn_field_collapse_table": (c_i, [c_p, c_p, c_u, c_f, c_u, c_p, c_p, c_p]),
+    "sdn_field_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    "sdn_field_encode": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
+                               ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "sdn_field_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                            c_p]),
+    "sdn_debug_mfma_probe": (c_i, [c_p, c_p, c_p, c_p]),
 }
 # entry points added by later kernels register themselves here (name -> (restype, argtypes))
 EXTRA_SIGNATURES = {}

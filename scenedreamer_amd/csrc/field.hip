@@ -1,0 +1,760 @@
+// Fused field renderer for gfx950: sample placement -> hash-grid lookup -> style-modulated MLP on
+// MFMA -> volume rendering + sky compositing.  Fast path for the reference's
+// Generator._forward_perpix / _forward_perpix_sub (imaginaire/generators/scenedreamer.py:285-430)
+// with mc_utils.sample_depth_batched (:82-151), GridEncoder.forward (gridencoder/grid.py:140-156),
+// LightningMLP.forward (imaginaire/model_utils/layers.py:92-126) and volum_rendering_relu
+// (mc_utils.py:154-161).
+//
+// Kernels
+//   collapse_kernel   once per scene.  The two trailing hash-grid coordinates (global_enc) are
+//                     constant per scene, and every level is hashed into a power-of-two table, so
+//                     (h ^ K) & m == (h & m) ^ (K & m) and the 32-corner 5-D blend factorises exactly
+//                     into an 8-corner 3-D blend of a per-scene table
+//                        T'[l][i] = sum_{c3,c4} w3 w4 T[l][i ^ K(c3,c4)]
+//                     (SURVEY.md appendix A).  4x fewer gathers per sample; only the fp32 summation
+//                     order differs from the reference.
+//   pack_kernel       once per style code.  Folded MLP weights (W * alpha) are split into f16 hi + f16 lo
+//                     and laid out in MFMA A-fragment order, so a wave fetches one fragment as one
+//                     fully coalesced 1 KiB access and no shuffles are needed anywhere.
+//   encode_kernel     per frame, one wave per 8 rays, 4 samples of every ray per step (32 MFMA columns):
+//                     places the samples (bit-identical decisions to the reference), blends the 16
+//                     levels from the collapsed table and writes the features directly in the MLP's
+//                     B-fragment order.  Pure gather: bound by L2 / Infinity-Cache / HBM bandwidth.
+//   mlp_kernel        per frame, persistent, one wave per SIMD (4 per CU), 32 samples per wave step.
+//                     The MLP is evaluated TRANSPOSED: D^T[feature][sample] = W[feature][k] * X[k][sample],
+//                     weights are the MFMA A operand, samples the B operand.  A wave keeps all 256
+//                     activations of its 32 samples in registers; the C/D register layout of one layer is
+//                     consumed directly as the B layout of the next (the k-permutation this implies is
+//                     baked into the packed weights), so activations never touch LDS or HBM.
+//                     Precision: the north star demands 1e-3 abs on radiance and the density head
+//                     amplifies hidden-activation error by ~1e2, which plain f16/bf16 MFMA misses by 10x
+//                     (measured).  Every product is therefore evaluated as a 3-term split
+//                     (Whi*Xhi + Wlo*Xhi + Whi*Xlo, f32 accumulate): ~2^-21 relative error at 3 f16 MFMAs
+//                     per tile, 5.3x the rate of the f32 MFMA.
+//                     Volume rendering, the density head, label bias, clamp and sky blend run in the
+//                     epilogues on the VALU.
+#include <hip/hip_fp16.h>
+
+#include "sdn_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int HID = 256;        // hidden width (layers.py:62)
+constexpr int FEAT = 128;       // hash-grid output width: 16 levels x 8 channels
+constexpr int OUTC = 64;        // colour feature width (final_feat_dim)
+constexpr int NLEV = 16;
+constexpr int NLAB = 12;
+constexpr int RAYS_PER_TILE = 8;
+constexpr int SAMP_PER_STEP = 4;
+constexpr int MAXM = 8;
+constexpr int MAX_LIN = 80;     // up to 78 samples per ray
+
+// ---- packed weight layout (in units of half8 = one lane's fragment) ---------------------------------
+// layer 0: fc_1   K=128 -> 8 k-steps, 8 row blocks
+// layer 1..5: fc_2..fc_6  K=256 -> 16 k-steps, 8 row blocks
+// layer 6: fc_out_c  K=256 -> 16 k-steps, 2 row blocks
+// fragment (s, ib, p) of a layer sits at ((s * nib + ib) * 2 + p) * 64 + lane,  p = 0 hi / 1 lo
+constexpr size_t L0_FRAGS = 8 * 8 * 2 * 64;
+constexpr size_t LH_FRAGS = 16 * 8 * 2 * 64;
+constexpr size_t LO_FRAGS = 16 * 2 * 2 * 64;
+constexpr size_t PACKED_FRAGS = L0_FRAGS + 5 * LH_FRAGS + LO_FRAGS;
+
+// ---- fp32 constant block ----------------------------------------------------------------------------
+constexpr int C_LABEL_BIAS = 0;                      // [12][256]  fc_m_a^T + fc_1.bias
+constexpr int C_BETA = C_LABEL_BIAS + NLAB * HID;    // [5][256]   ModLinear output bias
+constexpr int C_WSIGMA = C_BETA + 5 * HID;           // [256]
+constexpr int C_BC = C_WSIGMA + HID;                 // [64]
+constexpr int C_BSIGMA = C_BC + OUTC;                // [1]
+constexpr int C_SKY_AVG = C_BSIGMA + 4;              // [64]
+constexpr int C_TOTAL = C_SKY_AVG + OUTC;
+
+struct EncParams {
+    const int32_t *voxel_id;   // [R, M]
+    const float *depth2;       // [2, R, M]
+    const float *raydirs;      // [R, 3]
+    const uint8_t *lut;        // [1024] minecraft id -> reduced label (ignore already mapped to dirt)
+    const float *table3;       // [16][T][8] collapsed table
+    float *feat;               // [n_tiles][nch][8][64][8]
+    float *dist;               // [n_tiles][nch][32]  new_dists * dists_scale (0 for padding samples)
+    uint8_t *label;            // [n_tiles][nch][32]
+    uint8_t *rayflag;          // [R] bit0 sky_only, bit1 nosky
+    int32_t R, M, ns, nch, n_tiles;
+    uint32_t tmask;            // T - 1
+    float ori[3], delim[3];
+    float sample_depth, dists_scale;
+    int32_t genc_oob;          // global_enc outside [0,1] after mapping: every feature is zero
+    const float *lin;          // dev [ns+1]  linspace(0,1,ns+3)[1:-1] (torch.linspace on the host side)
+    const float *scales;       // dev [16]    per-level scale, exp2f(l*S)*H-1 evaluated on the host
+};
+
+struct MlpParams {
+    const float *feat;
+    const float *dist;
+    const uint8_t *label;
+    const uint8_t *rayflag;
+    const half8 *wpk;          // packed weights
+    const float *consts;       // fp32 constant block
+    const float *sky_c;        // [R, 64] sky_net output per ray
+    float *net_out;            // [R, 64]
+    int32_t R, ns, nch, n_tiles;
+};
+
+// =====================================================================================================
+// collapse
+// =====================================================================================================
+struct CollapseParams {
+    const float *emb;   // original table, level l at emb + off[l] * 8
+    float *table3;
+    uint32_t T;
+    uint32_t off[NLEV];
+    uint32_t K[NLEV][4];   // hash contribution of corner (c3, c4), index c3 + 2*c4, already & (T-1)
+    float w[NLEV][4];      // w3 * w4 with the reference's multiply order
+};
+
+__global__ __launch_bounds__(256) void collapse_kernel(const CollapseParams p) {
+    const uint32_t level = blockIdx.y;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.T) return;
+    const float *src = p.emb + (size_t)p.off[level] * 8;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {  // c3 fastest, like the corner index of the reference loop
+        const float4 a = *reinterpret_cast<const float4 *>(src + (size_t)(i ^ p.K[level][c]) * 8);
+        const float4 b = *reinterpret_cast<const float4 *>(src + (size_t)(i ^ p.K[level][c]) * 8 + 4);
+        const float w = p.w[level][c];
+        acc[0] += w * a.x; acc[1] += w * a.y; acc[2] += w * a.z; acc[3] += w * a.w;
+        acc[4] += w * b.x; acc[5] += w * b.y; acc[6] += w * b.z; acc[7] += w * b.w;
+    }
+    float *dst = p.table3 + ((size_t)level * p.T + i) * 8;
+    *reinterpret_cast<float4 *>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    *reinterpret_cast<float4 *>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+}
+
+// =====================================================================================================
+// weight packing
+// =====================================================================================================
+// k index that element e of lane-half h holds in k-step s of the B operand
+__host__ __device__ inline int kmap_first(int s, int h, int e) { return 16 * s + 8 * h + e; }
+__host__ __device__ inline int kmap_hidden(int s, int h, int e) {
+    // C/D layout of v_mfma_f32_32x32x16: register r of lane-half h holds row (r&3) + 8*(r>>2) + 4*h;
+    // k-step s consumes registers 8*(s&1) .. 8*(s&1)+7 of row block s>>1
+    return 32 * (s >> 1) + 16 * (s & 1) + (e & 3) + 8 * (e >> 2) + 4 * h;
+}
+
+struct PackParams {
+    const float *w1;      // [256,128]
+    const float *wh[5];   // [256,256] each, W * alpha already folded
+    const float *wc;      // [64,256]
+    half8 *out;
+};
+
+__global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (layer, s, ib, lane)
+    const size_t n0 = 8 * 8 * 64, nh = 16 * 8 * 64, no = 16 * 2 * 64;
+    if (g >= n0 + 5 * nh + no) return;
+    int layer, s, ib, lane, nib, K;
+    const float *W;
+    size_t base, r = g;
+    if (r < n0) {
+        layer = 0; nib = 8; K = FEAT; W = p.w1; base = 0;
+    } else if (r < n0 + 5 * nh) {
+        r -= n0; layer = 1 + (int)(r / nh); r %= nh; nib = 8; K = HID; W = p.wh[layer - 1];
+        base = L0_FRAGS + (size_t)(layer - 1) * LH_FRAGS;
+    } else {
+        r -= n0 + 5 * nh; layer = 6; nib = 2; K = HID; W = p.wc; base = L0_FRAGS + 5 * LH_FRAGS;
+    }
+    lane = (int)(r % 64); r /= 64;
+    ib = (int)(r % nib);
+    s = (int)(r / nib);
+    const int row = 32 * ib + (lane & 31), h = lane >> 5;
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = layer == 0 ? kmap_first(s, h, e) : kmap_hidden(s, h, e);
+        const float v = W[(size_t)row * K + k];
+        const _Float16 vh = (_Float16)v;
+        hi[e] = vh;
+        lo[e] = (_Float16)(v - (float)vh);
+    }
+    p.out[base + ((size_t)(s * nib + ib) * 2 + 0) * 64 + lane] = hi;
+    p.out[base + ((size_t)(s * nib + ib) * 2 + 1) * 64 + lane] = lo;
+}
+
+// =====================================================================================================
+// encode: sample placement + collapsed hash-grid lookup
+// =====================================================================================================
+struct RayBoxes {
+    float t[MAXM], t2[MAXM];
+    int32_t id[MAXM];
+};
+
+// Everything that feeds a DISCRETE decision of the reference (box index of a sample, the is_gnd test,
+// the grid cell) is evaluated with exactly the reference's fp32 operation sequence: no FMA contraction.
+struct Placed {
+    float depth, dist;
+    int idx;
+};
+
+__device__ __forceinline__ Placed place_sample(const RayBoxes &rb, int M, const float *lin, int sidx, float sample_depth) {
+#pragma clang fp contract(off)
+    // mc_utils.py:101-107.  torch.cumsum on the CPU (what the oracle and the golden vectors were produced
+    // with) accumulates float32 inputs in double and rounds every prefix back to float; it is mirrored here
+    // because a 1-ulp change of a sample depth moves a fine-level feature by up to ~1e-4.
+    float accu[MAXM];
+    double run_d = 0.0;
+    float run = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXM; k++) {
+        if (k < M) {
+            float d = rb.t2[k] - rb.t[k];
+            if (d != d) d = 0.f;
+            run_d += (double)d;
+            run = (float)run_d;
+            accu[k] = run;
+        } else {
+            accu[k] = 0.f;
+        }
+    }
+    const float total = fminf(run, sample_depth);
+    // :118-135 deterministic stratified points and their midpoints
+    const float s0 = lin[sidx] * total, s1 = lin[sidx + 1] * total;
+    const float mid = (s1 + s0) / 2.f;
+    Placed o;
+    o.dist = s1 - s0;
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < MAXM; k++)
+        if (k < M && mid > accu[k]) idx++;  // :139
+    // :142-145 head of the box the sample falls into: t[0] + cumulative gaps
+    float head = rb.t[0];
+    double cg_d = 0.0;
+#pragma unroll
+    for (int k = 1; k < MAXM; k++) {
+        if (k < M) {
+            const float g = rb.t[k] - rb.t2[k - 1];
+            cg_d += (double)g;
+            const float cg = (float)cg_d;
+            if (k == idx) head = cg + rb.t[0];
+        }
+    }
+    float depth = head + mid;  // :149
+    if (depth != depth || __builtin_isinf(depth)) depth = 0.f;  // scenedreamer.py:350-352
+    o.depth = depth;
+    o.idx = idx < M ? idx : M - 1;
+    return o;
+}
+
+__device__ __forceinline__ float mul_add_exact(float a, float b, float c) {
+#pragma clang fp contract(off)
+    const float p = a * b;
+    return p + c;
+}
+
+__device__ __forceinline__ float normalise_coord(float wc, float delim) {
+#pragma clang fp contract(off)
+    // scenedreamer.py:300 then grid.py:144:  ((wc / delim * 2 - 1) + 1) / 2
+    float n = wc / delim;
+    n = n * 2.f;
+    n = n - 1.f;
+    n = n + 1.f;
+    return n / 2.f;
+}
+
+__global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= p.n_tiles) return;
+    const int h = lane >> 5, j = lane & 31;
+    const int ray = tile * RAYS_PER_TILE + (j >> 2);
+    const bool ray_ok = ray < p.R;
+    const int rr = ray_ok ? ray : p.R - 1;
+
+    RayBoxes rb;
+#pragma unroll
+    for (int k = 0; k < MAXM; k++) {
+        if (k < p.M) {
+            rb.t[k] = p.depth2[(size_t)rr * p.M + k];
+            rb.t2[k] = p.depth2[((size_t)p.R + rr) * p.M + k];
+            rb.id[k] = p.voxel_id[(size_t)rr * p.M + k];
+        } else {
+            rb.t[k] = rb.t2[k] = __builtin_nanf("");
+            rb.id[k] = 0;
+        }
+    }
+    const float d0 = p.raydirs[(size_t)rr * 3], d1 = p.raydirs[(size_t)rr * 3 + 1], d2 = p.raydirs[(size_t)rr * 3 + 2];
+    bool gnd = false;
+
+    for (int ch = 0; ch < p.nch; ch++) {
+        const int sidx = ch * SAMP_PER_STEP + (j & 3);
+        const bool valid = ray_ok && sidx < p.ns;
+        const Placed pl = place_sample(rb, p.M, p.lin, valid ? sidx : 0, p.sample_depth);
+        const float wx = mul_add_exact(d0, pl.depth, p.ori[0]);  // scenedreamer.py:354
+        const float wy = mul_add_exact(d1, pl.depth, p.ori[1]);
+        const float wz = mul_add_exact(d2, pl.depth, p.ori[2]);
+        if (valid && wx <= 1.0f) gnd = true;                    // :380
+        const float x0 = normalise_coord(wx, p.delim[0]);
+        const float x1 = normalise_coord(wy, p.delim[1]);
+        const float x2 = normalise_coord(wz, p.delim[2]);
+        const bool oob = p.genc_oob || x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f || x2 < 0.f || x2 > 1.f;
+
+        const size_t tc = (size_t)tile * p.nch + ch;
+        if (h == 0) {
+            p.dist[tc * 32 + j] = valid ? pl.dist * p.dists_scale : 0.f;
+            int id = rb.id[0];
+#pragma unroll
+            for (int k = 1; k < MAXM; k++)
+                if (k == pl.idx) id = rb.id[k];
+            p.label[tc * 32 + j] = p.lut[id & 1023];
+        }
+        float *fout = p.feat + (tc * 8 * 64 + lane) * 8;
+#pragma unroll 2
+        for (int s = 0; s < 8; s++) {
+            const int level = 2 * s + h;
+            float res[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (!oob && valid) {
+                const float scale = p.scales[level];
+                float f0 = mul_add_exact(x0, scale, 0.5f), f1 = mul_add_exact(x1, scale, 0.5f),
+                      f2 = mul_add_exact(x2, scale, 0.5f);
+                const float g0 = floorf(f0), g1 = floorf(f1), g2 = floorf(f2);
+                f0 -= g0; f1 -= g1; f2 -= g2;
+                const uint32_t a0 = (uint32_t)g0, a1 = (uint32_t)g1 * 2654435761u, a2 = (uint32_t)g2 * 805459861u;
+                const uint32_t b0 = a0 + 1u, b1 = a1 + 2654435761u, b2 = a2 + 805459861u;
+                const float *tb = p.table3 + (size_t)level * ((size_t)p.tmask + 1) * 8;
+                float4 va[8], vb[8];
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    const uint32_t hsh = ((c & 1) ? b0 : a0) ^ ((c & 2) ? b1 : a1) ^ ((c & 4) ? b2 : a2);
+                    const float *row = tb + (size_t)(hsh & p.tmask) * 8;
+                    va[c] = *reinterpret_cast<const float4 *>(row);
+                    vb[c] = *reinterpret_cast<const float4 *>(row + 4);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    float w = 1.f;  // same multiply order as gridencoder.cu:152-160
+                    w *= (c & 1) ? f0 : 1.f - f0;
+                    w *= (c & 2) ? f1 : 1.f - f1;
+                    w *= (c & 4) ? f2 : 1.f - f2;
+                    res[0] += w * va[c].x; res[1] += w * va[c].y; res[2] += w * va[c].z; res[3] += w * va[c].w;
+                    res[4] += w * vb[c].x; res[5] += w * vb[c].y; res[6] += w * vb[c].z; res[7] += w * vb[c].w;
+                }
+            }
+            float *o = fout + (size_t)s * 64 * 8;
+            *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(res[4], res[5], res[6], res[7]);
+        }
+    }
+    // per-ray flags: any over the ray's 4 lanes
+    gnd = __shfl_xor((int)gnd, 1) | (int)gnd;
+    gnd = __shfl_xor((int)gnd, 2) | (int)gnd;
+    if (h == 0 && (j & 3) == 0 && ray_ok) {
+        const bool sky_only = rb.id[0] == 0;             // scenedreamer.py:337
+        int last = rb.id[0];
+#pragma unroll
+        for (int k = 1; k < MAXM; k++)
+            if (k == p.M - 1) last = rb.id[k];
+        const bool nosky = (last != 0) || gnd;           // :335, :382
+        p.rayflag[ray] = (uint8_t)((sky_only ? 1 : 0) | (nosky ? 2 : 0));
+    }
+}
+
+// =====================================================================================================
+// MLP + compositing
+// =====================================================================================================
+__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8 &hi, half8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const _Float16 x = (_Float16)v[e];
+        hi[e] = x;
+        lo[e] = (_Float16)(v[e] - (float)x);
+    }
+}
+
+// acc[ib][r] = vec[32*ib + (r&3) + 8*(r>>2) + 4*h] : the per-lane view of a 256 (or 64) vector
+template <int NIB>
+__device__ __forceinline__ void load_rowvec(const float *__restrict__ vec, int h, f32x16 (&acc)[NIB]) {
+#pragma unroll
+    for (int ib = 0; ib < NIB; ib++) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 v = *reinterpret_cast<const float4 *>(vec + 32 * ib + 8 * g + 4 * h);
+            acc[ib][4 * g + 0] = v.x; acc[ib][4 * g + 1] = v.y; acc[ib][4 * g + 2] = v.z; acc[ib][4 * g + 3] = v.w;
+        }
+    }
+}
+
+// One dense layer, transposed: acc[ib] += W[32 ib.., k-step s] * X[k-step s, 32 samples], 3-term f16 split.
+// Work is cut into "units" of two row blocks of one k-step (4 A fragments, 6 MFMAs = 192 matrix-pipe cycles).
+// A 4-deep register ring keeps 3 units of fragment loads (12 x 1 KiB per wave) in flight ahead of the MFMAs,
+// i.e. ~580 cycles of cover for the L2 round trip; sched_barrier pins that distance (left alone, the compiler
+// front-loads a whole layer and spills a thousand registers).
+// Fragment fetch through a buffer descriptor: the address is {SGPR base, one VGPR lane offset, scalar offset}.
+// With flat pointers the compiler materialises (and then spills) one 64-bit VGPR address per fragment.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ half8 load_frag(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0);
+    return __builtin_bit_cast(half8, v);
+}
+
+template <int NIB>
+__device__ __forceinline__ void load_unit(__amdgpu_buffer_rsrc_t rsrc, int u, int lane_off, half8 (&a)[4]) {
+    constexpr int PAIRS = NIB / 2;
+    const int s = u / PAIRS, ib = 2 * (u % PAIRS);
+    const int base = ((s * NIB + ib) * 2) * 1024;  // bytes; fragment (s, ib, p) is 1 KiB
+    a[0] = load_frag(rsrc, lane_off, base);          // hi, row block ib
+    a[1] = load_frag(rsrc, lane_off, base + 1024);   // lo, row block ib
+    a[2] = load_frag(rsrc, lane_off, base + 2048);   // hi, row block ib+1
+    a[3] = load_frag(rsrc, lane_off, base + 3072);   // lo, row block ib+1
+}
+
+template <int NIB, int NSTEPS>
+__device__ __forceinline__ void gemm_layer(const half8 *wp, int lane, const half8 (&bh)[16],
+                                           const half8 (&bl)[16], f32x16 (&acc)[NIB]) {
+    constexpr int PAIRS = NIB / 2, UNITS = NSTEPS * PAIRS, RD = 4;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(wp), 0, NSTEPS * NIB * 2 * 1024, 0x00020000);
+    const int lane_off = lane * 16;
+    half8 ring[RD][4];
+#pragma unroll
+    for (int u = 0; u < RD - 1; u++) load_unit<NIB>(rsrc, u, lane_off, ring[u]);
+#pragma unroll
+    for (int u = 0; u < UNITS; u++) {
+        if (u + RD - 1 < UNITS) load_unit<NIB>(rsrc, u + RD - 1, lane_off, ring[(u + RD - 1) % RD]);
+        const int s = u / PAIRS, ib = 2 * (u % PAIRS);
+        half8(&a)[4] = ring[u % RD];
+        acc[ib] = mfma16(a[0], bh[s], acc[ib]);
+        acc[ib + 1] = mfma16(a[2], bh[s], acc[ib + 1]);
+        acc[ib] = mfma16(a[1], bh[s], acc[ib]);
+        acc[ib + 1] = mfma16(a[3], bh[s], acc[ib + 1]);
+        acc[ib] = mfma16(a[0], bl[s], acc[ib]);
+        acc[ib + 1] = mfma16(a[2], bl[s], acc[ib + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Bias + activation + re-split of a finished layer: the C/D registers become the next layer's B fragments.
+// bias is the per-output-feature vector (beta of the ModLinear, or the label-bias row for fc_1); it is fetched
+// in 8-float pieces right where it is consumed so that it never occupies registers next to the accumulators.
+__device__ __forceinline__ void activate(f32x16 (&acc)[8], const float *__restrict__ bias, int h, half8 (&bh)[16],
+                                         half8 (&bl)[16]) {
+#pragma unroll
+    for (int ib = 0; ib < 8; ib++) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float4 b0 = *reinterpret_cast<const float4 *>(bias + 32 * ib + 16 * q + 4 * h);
+            const float4 b1 = *reinterpret_cast<const float4 *>(bias + 32 * ib + 16 * q + 8 + 4 * h);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                v[e] = lrelu(acc[ib][8 * q + e] + bb[e]);
+                acc[ib][8 * q + e] = v[e];
+            }
+            split8(v, bh[2 * ib + q], bl[2 * ib + q]);
+        }
+    }
+}
+
+template <int NIB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NIB]) {
+#pragma unroll
+    for (int ib = 0; ib < NIB; ib++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[ib][r] = 0.f;
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const float *cst = p.consts;
+
+    for (int tile = blockIdx.x * 4 + wave; tile < p.n_tiles; tile += gridDim.x * 4) {
+        const int ray = tile * RAYS_PER_TILE + (j >> 2);
+        const bool ray_ok = ray < p.R;
+        const uint8_t flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
+        // wave-uniform: nothing to integrate when none of the 8 rays hits anything
+        const bool any_hit = __any(!(flag & 1));
+
+        // lane (ray, q = j&3, h) ends up owning output features 32*ib + 8*q + 4*h + {0..3}, ib = 0,1
+        float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        const int q = j & 3;
+        float carry = 0.f, tsum = 0.f;
+
+        for (int ch = 0; any_hit && ch < p.nch; ch++) {
+            const size_t tc = (size_t)tile * p.nch + ch;
+            half8 bh[16], bl[16];
+            f32x16 acc[8];
+            // ---- layer fc_1: features (B) and label bias (C init) ----------------------------------
+            {
+                const float *fin = p.feat + (tc * 8 * 64 + lane) * 8;
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const float4 a = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8);
+                    const float4 b = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8 + 4);
+                    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    split8(v, bh[s], bl[s]);
+                }
+                const int lab = p.label[tc * 32 + j];
+                zero_acc<8>(acc);
+                gemm_layer<8, 8>(p.wpk, lane, bh, bl, acc);
+                activate(acc, cst + C_LABEL_BIAS + lab * HID, h, bh, bl);
+            }
+            // ---- fc_2 .. fc_6 ----------------------------------------------------------------------
+            float sigma = 0.f;
+#pragma unroll 1
+            for (int l = 0; l < 5; l++) {
+                zero_acc<8>(acc);
+                gemm_layer<8, 16>(p.wpk + L0_FRAGS + (size_t)l * LH_FRAGS, lane, bh, bl, acc);
+                activate(acc, cst + C_BETA + l * HID, h, bh, bl);
+                if (l == 2) {  // density head on the fp32 activations of fc_4 (layers.py:114)
+                    float part = 0.f;
+#pragma unroll
+                    for (int ib = 0; ib < 8; ib++) {
+#pragma unroll
+                        for (int g = 0; g < 4; g++) {
+                            const float4 w = *reinterpret_cast<const float4 *>(cst + C_WSIGMA + 32 * ib + 8 * g + 4 * h);
+                            part += w.x * acc[ib][4 * g] + w.y * acc[ib][4 * g + 1] + w.z * acc[ib][4 * g + 2] +
+                                    w.w * acc[ib][4 * g + 3];
+                        }
+                    }
+                    sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
+                }
+            }
+            // ---- fc_out_c ----------------------------------------------------------------------------
+            f32x16 col[2];
+            load_rowvec<2>(cst + C_BC, h, col);
+            gemm_layer<2, 16>(p.wpk + L0_FRAGS + 5 * LH_FRAGS, lane, bh, bl, col);
+            // ---- volume rendering (mc_utils.py:154-161) over the 4 samples of each ray in this step ----
+            const float fe = fmaxf(sigma, 0.f) * p.dist[tc * 32 + j];
+            // exclusive prefix within the quad (samples are lanes j&3 = 0..3 in ray order)
+            float incl = fe;
+            float up = __shfl_up(incl, 1, 4);
+            if ((j & 3) >= 1) incl += up;
+            up = __shfl_up(incl, 2, 4);
+            if ((j & 3) >= 2) incl += up;
+            float ex = __shfl_up(incl, 1, 4);
+            if ((j & 3) == 0) ex = 0.f;
+            const float excl = carry + ex;
+            const float wgt = (1.f - __expf(-fe)) * __expf(-excl);
+            carry += __shfl(incl, 3, 4);
+            tsum += wgt;
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float rgb = fminf(fmaxf(col[ib][r], -1.f), 1.f) + 1.f;  // scenedreamer.py:408
+                    float v = wgt * rgb;
+                    v += __shfl_xor(v, 1);   // sum over the 4 samples of the ray held by this quad
+                    v += __shfl_xor(v, 2);
+                    if ((r >> 2) == q) outq[ib][r & 3] += v;
+                }
+        }
+
+        // ---- reduce the ray's 4 lanes, blend the sky, store -------------------------------------------
+        tsum += __shfl_xor(tsum, 1);
+        tsum += __shfl_xor(tsum, 2);
+        const bool sky_only = flag & 1, nosky = flag & 2;
+        if (sky_only) tsum = 0.f;  // scenedreamer.py:376
+        const float sky_w = 1.f - tsum;
+        if (ray_ok) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) {
+                {
+                    {
+                        const int f0 = 32 * ib + 8 * q + 4 * h;
+                        const float4 sc = *reinterpret_cast<const float4 *>(p.sky_c + (size_t)ray * OUTC + f0);
+                        const float4 sa = *reinterpret_cast<const float4 *>(cst + C_SKY_AVG + f0);
+                        float o[4];
+                        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sav[4] = {sa.x, sa.y, sa.z, sa.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float sky = nosky ? (scv[e] * 0.f + sav[e]) : scv[e];  // :401 with mask in {0,1}
+                            const float rgb_sky = fminf(fmaxf(sky, -1.f), 1.f) + 1.f;
+                            o[e] = (sky_only ? 0.f : outq[ib][e]) + sky_w * rgb_sky - 1.f;  // :410-413
+                        }
+                        *reinterpret_cast<float4 *>(p.net_out + (size_t)ray * OUTC + f0) = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// debug probe: checks the MFMA operand layouts this file relies on (tests/test_fused_gpu.py)
+// =====================================================================================================
+__global__ void mfma_probe_kernel(const float *A, const float *B, float *C) {
+    // A [32][16], B [16][32] row-major fp32 -> C [32][32]
+    const int lane = threadIdx.x, h = lane >> 5, j = lane & 31;
+    half8 a, b;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        a[e] = (_Float16)A[j * 16 + 8 * h + e];
+        b[e] = (_Float16)B[(8 * h + e) * 32 + j];
+    }
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; r++) c[r] = 0.f;
+    c = mfma16(a, b, c);
+#pragma unroll
+    for (int r = 0; r < 16; r++) C[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = c[r];
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+size_t sdn_field_packed_weight_bytes(void) { return PACKED_FRAGS * sizeof(half8); }
+size_t sdn_field_consts_floats(void) { return C_TOTAL; }
+int sdn_field_const_offset(int which) {
+    switch (which) {
+        case 0: return C_LABEL_BIAS;
+        case 1: return C_BETA;
+        case 2: return C_WSIGMA;
+        case 3: return C_BC;
+        case 4: return C_BSIGMA;
+        case 5: return C_SKY_AVG;
+        default: return -1;
+    }
+}
+
+int sdn_field_collapse_table(const float *embeddings, const int32_t *offsets_host, uint32_t L, float S, uint32_t H,
+                             const float *genc_host, float *table3, sdn_stream_t stream) {
+    SDN_REQUIRE(embeddings && offsets_host && genc_host && table3, "sdn_field_collapse_table: null pointer");
+    if (L != NLEV) return sdn::fail(SDN_ERR_UNSUPPORTED, "fused field path needs the 16-level SceneDreamer grid");
+    CollapseParams p;
+    p.emb = embeddings;
+    p.table3 = table3;
+    const uint32_t T = (uint32_t)(offsets_host[1] - offsets_host[0]);
+    if (T == 0 || (T & (T - 1)) != 0)
+        return sdn::fail(SDN_ERR_UNSUPPORTED, "fused field path needs a power-of-two hash table per level");
+    p.T = T;
+    for (uint32_t l = 0; l < L; l++) {
+        if ((uint32_t)(offsets_host[l + 1] - offsets_host[l]) != T)
+            return sdn::fail(SDN_ERR_UNSUPPORTED, "fused field path needs equally sized levels");
+        const float scale = exp2f((float)l * S) * (float)H - 1.0f;
+        const uint32_t res = (uint32_t)ceilf(scale) + 1;
+        // every level must take the hash branch of get_grid_index (gridencoder.cu:60-69) on the 5-D grid
+        double stride = 1;
+        for (int d = 0; d < 5 && stride <= (double)T; d++) stride *= (double)(res + 1);
+        if (!(stride > (double)T))
+            return sdn::fail(SDN_ERR_UNSUPPORTED, "fused field path needs every level hashed (level %u is dense)", l);
+        p.off[l] = (uint32_t)offsets_host[l];
+        float fr[2];
+        uint32_t pg[2];
+        for (int d = 0; d < 2; d++) {
+            const float x = (genc_host[d] + 1.f) / 2.f;  // grid.py:144
+            volatile float prod = x * scale;             // two roundings, like the kernels
+            const float pos = prod + 0.5f;
+            const float fl = floorf(pos);
+            pg[d] = (uint32_t)fl;
+            fr[d] = pos - fl;
+        }
+        for (int c = 0; c < 4; c++) {
+            const int c3 = c & 1, c4 = c >> 1;
+            const uint32_t k = ((pg[0] + c3) * 3674653429u) ^ ((pg[1] + c4) * 2097192037u);
+            p.K[l][c] = k & (T - 1);
+            // reference multiply order: ((((1*w0)*w1)*w2)*w3)*w4 -> here the trailing w3*w4 factor
+            volatile float w3 = c3 ? fr[0] : 1.f - fr[0];
+            volatile float w4 = c4 ? fr[1] : 1.f - fr[1];
+            p.w[l][c] = w3 * w4;
+        }
+    }
+    hipLaunchKernelGGL(collapse_kernel, dim3(sdn::div_up<uint32_t>(T, 256), L), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_field_collapse_table");
+}
+
+int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const float *wc, void *packed,
+                           sdn_stream_t stream) {
+    SDN_REQUIRE(w1 && wh5_host && wc && packed, "sdn_field_pack_weights: null pointer");
+    PackParams p;
+    p.w1 = w1;
+    for (int i = 0; i < 5; i++) {
+        SDN_REQUIRE(wh5_host[i], "sdn_field_pack_weights: null hidden weight");
+        p.wh[i] = wh5_host[i];
+    }
+    p.wc = wc;
+    p.out = (half8 *)packed;
+    const size_t n = 8 * 8 * 64 + 5 * 16 * 8 * 64 + 16 * 2 * 64;
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)sdn::div_up<size_t>(n, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_field_pack_weights");
+}
+
+size_t sdn_field_feat_bytes(int32_t n_rays, int32_t num_samples) {
+    const size_t tiles = (size_t)sdn::div_up(n_rays, RAYS_PER_TILE), nch = (size_t)sdn::div_up(num_samples, SAMP_PER_STEP);
+    return tiles * nch * 8 * 64 * 8 * sizeof(float);
+}
+size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples) {
+    const size_t tiles = (size_t)sdn::div_up(n_rays, RAYS_PER_TILE), nch = (size_t)sdn::div_up(num_samples, SAMP_PER_STEP);
+    return tiles * nch * 32;
+}
+
+int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
+                     const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
+                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, int32_t n_rays,
+                     int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
+                     float *dist, uint8_t *label, uint8_t *rayflag, sdn_stream_t stream) {
+    SDN_REQUIRE(voxel_id && depth2 && raydirs && lut1024 && table3 && scales_dev && genc_host && cam_ori_host &&
+                    voxel_dims_host && lin_dev && feat && dist && label && rayflag,
+                "sdn_field_encode: null pointer");
+    SDN_REQUIRE(n_rays > 0 && num_samples > 0, "sdn_field_encode: empty frame");
+    if (max_blocks < 1 || max_blocks > MAXM) return sdn::fail(SDN_ERR_UNSUPPORTED, "sdn_field_encode: max_blocks must be 1..8");
+    if (num_samples + 1 > MAX_LIN) return sdn::fail(SDN_ERR_UNSUPPORTED, "sdn_field_encode: at most 79 samples per ray");
+    SDN_REQUIRE(table_rows && (table_rows & (table_rows - 1)) == 0, "sdn_field_encode: table_rows must be a power of two");
+    EncParams p;
+    p.voxel_id = voxel_id; p.depth2 = depth2; p.raydirs = raydirs; p.lut = lut1024; p.table3 = table3;
+    p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag;
+    p.R = n_rays; p.M = max_blocks; p.ns = num_samples;
+    p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
+    p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
+    p.tmask = table_rows - 1;
+    p.genc_oob = 0;
+    for (int d = 0; d < 2; d++) {
+        const float x = (genc_host[d] + 1.f) / 2.f;
+        if (x < 0.f || x > 1.f) p.genc_oob = 1;
+    }
+    for (int i = 0; i < 3; i++) { p.ori[i] = cam_ori_host[i]; p.delim[i] = voxel_dims_host[i]; }
+    p.sample_depth = sample_depth; p.dists_scale = dists_scale;
+    p.lin = lin_dev;
+    p.scales = scales_dev;
+    hipLaunchKernelGGL(encode_kernel, dim3(sdn::div_up(p.n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_field_encode");
+}
+
+int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
+                  const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
+                  int32_t n_workgroups, sdn_stream_t stream) {
+    SDN_REQUIRE(feat && dist && label && rayflag && packed && consts && sky_c && net_out, "sdn_field_mlp: null pointer");
+    SDN_REQUIRE(n_rays > 0 && num_samples > 0, "sdn_field_mlp: empty frame");
+    MlpParams p;
+    p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag; p.wpk = (const half8 *)packed;
+    p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
+    p.R = n_rays; p.ns = num_samples;
+    p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
+    p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
+    int wg = n_workgroups > 0 ? n_workgroups : 256;
+    const int need = sdn::div_up(p.n_tiles, 4);
+    if (wg > need) wg = need;
+    hipLaunchKernelGGL(mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_field_mlp");
+}
+
+int sdn_debug_mfma_probe(const float *A, const float *B, float *C, sdn_stream_t stream) {
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, A, B, C);
+    return sdn::check_launch("sdn_debug_mfma_probe");
+}
+
+}  // extern "C"

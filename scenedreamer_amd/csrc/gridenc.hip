@@ -431,6 +431,16 @@ int launch_bwd_d(const float *grad, const float *inputs, const int32_t *offsets,
 
 }  // namespace
 
+extern "C" int sdn_grid_level_scales(uint32_t L, float S, uint32_t H, float *scales_host, uint32_t *resolutions_host) {
+    SDN_REQUIRE(scales_host, "sdn_grid_level_scales: null pointer");
+    for (uint32_t l = 0; l < L; l++) {
+        const float sc = exp2f((float)l * S) * (float)H - 1.0f;  // gridencoder.cu:126
+        scales_host[l] = sc;
+        if (resolutions_host) resolutions_host[l] = (uint32_t)ceilf(sc) + 1;  // :127
+    }
+    return SDN_OK;
+}
+
 extern "C" int sdn_grid_encode_fwd(const float *inputs, const void *embeddings, int emb_dtype, const int32_t *offsets,
                                    void *outputs, uint32_t B, uint32_t D, uint32_t C, uint32_t L, float S, uint32_t H,
                                    int calc_grad_inputs, void *dy_dx, uint32_t gridtype, int align_corners,

@@ -1,0 +1,124 @@
+"""Host side of the fused field renderer (csrc/field.hip): per-scene / per-style preparation and the
+per-frame encode -> mlp launches.  PyTorch only provides device memory and the stream."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import capi
+
+_f2 = ctypes.c_float * 2
+_f3 = ctypes.c_float * 3
+
+
+def _lib():
+    return capi.lib()
+
+
+def _stream(dev):
+    return capi.current_stream(dev)
+
+
+def prepare_scene(R):
+    """Collapse the 5-D hash table with this scene's global_enc (once per scene)."""
+    lib = _lib()
+    offs = R.w["hash_encoder.offsets"].cpu().numpy().astype(np.int32)
+    L = offs.size - 1
+    T = int(offs[1] - offs[0])
+    genc = R.global_enc.detach().cpu().numpy().astype(np.float32).reshape(2)
+    table3 = torch.empty((L, T, 8), dtype=torch.float32, device=R.dev)
+    with torch.cuda.device(R.dev):
+        rc = lib.sdn_field_collapse_table(R.w["hash_encoder.embeddings"].data_ptr(), offs.ctypes.data, L,
+                                          float(np.float32(R.grid_S)), 16, genc.ctypes.data, table3.data_ptr(),
+                                          _stream(R.dev))
+    capi.check(rc, "sdn_field_collapse_table")
+    scales = np.empty(L, np.float32)
+    capi.check(lib.sdn_grid_level_scales(L, float(np.float32(R.grid_S)), 16, scales.ctypes.data, None))
+    lut = torch.full((1024,), 3, dtype=torch.uint8)
+    n = min(R.lut.numel(), 1024)
+    lut[:n] = R.lut[:n].to(torch.uint8).cpu()
+    R._fused_scene = dict(table3=table3, T=T, genc=genc, scales=torch.from_numpy(scales).to(R.dev),
+                          lut=lut.to(R.dev), dims=np.asarray([float(v) for v in R.voxel_t.shape], np.float32))
+    return R._fused_scene
+
+
+def prepare_style(R):
+    """Pack the folded MLP weights into MFMA fragment order + build the fp32 constant block (once per style)."""
+    lib = _lib()
+    w = R.w
+    packed = torch.empty(lib.sdn_field_packed_weight_bytes(), dtype=torch.uint8, device=R.dev)
+    wh = [R.mod[i][0].contiguous() for i in (2, 3, 4, 5, 6)]
+    ptrs = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in wh])
+    w1 = w["render_net.fc_1.weight"].contiguous()
+    wc = w["render_net.fc_out_c.weight"].contiguous()
+    with torch.cuda.device(R.dev):
+        rc = lib.sdn_field_pack_weights(w1.data_ptr(), ptrs, wc.data_ptr(), packed.data_ptr(), _stream(R.dev))
+    capi.check(rc, "sdn_field_pack_weights")
+    consts = torch.zeros(lib.sdn_field_consts_floats(), dtype=torch.float32, device=R.dev)
+    off = [lib.sdn_field_const_offset(i) for i in range(6)]
+    consts[off[0]:off[0] + 12 * 256] = R.label_bias.reshape(-1)
+    consts[off[1]:off[1] + 5 * 256] = torch.stack([R.mod[i][1] for i in (2, 3, 4, 5, 6)]).reshape(-1)
+    consts[off[2]:off[2] + 256] = w["render_net.fc_sigma.weight"].reshape(-1)
+    consts[off[3]:off[3] + 64] = w["render_net.fc_out_c.bias"]
+    consts[off[4]] = w["render_net.fc_sigma.bias"].reshape(-1)[0]
+    R._fused_style = dict(packed=packed, consts=consts, sky_off=off[5], keep=wh)
+    return R._fused_style
+
+
+def _buffers(R, n_rays, ns):
+    key = (n_rays, ns)
+    cache = R.__dict__.setdefault("_fused_buf", {})
+    if key not in cache:
+        lib = _lib()
+        cache.clear()
+        aux = lib.sdn_field_aux_elems(n_rays, ns)
+        cache[key] = dict(
+            feat=torch.empty(lib.sdn_field_feat_bytes(n_rays, ns) // 4, dtype=torch.float32, device=R.dev),
+            dist=torch.empty(aux, dtype=torch.float32, device=R.dev),
+            label=torch.empty(aux, dtype=torch.uint8, device=R.dev),
+            rayflag=torch.empty(n_rays, dtype=torch.uint8, device=R.dev),
+            lin=torch.linspace(0, 1, ns + 3)[1:-1].contiguous().to(R.dev),  # mc_utils.py:120
+        )
+    return cache[key]
+
+
+def encode(R, vid, d2, rd, cam_ori, ns, buf=None):
+    sc = R._fused_scene or prepare_scene(R)
+    n_rays = vid.shape[0]
+    buf = buf or _buffers(R, n_rays, ns)
+    ori = np.asarray(cam_ori.detach().cpu().numpy() if isinstance(cam_ori, torch.Tensor) else cam_ori, np.float32)
+    with torch.cuda.device(R.dev):
+        rc = _lib().sdn_field_encode(vid.data_ptr(), d2.data_ptr(), rd.data_ptr(), sc["lut"].data_ptr(),
+                                     sc["table3"].data_ptr(), sc["T"], sc["scales"].data_ptr(),
+                                     sc["genc"].ctypes.data, ori.ctypes.data, sc["dims"].ctypes.data,
+                                     buf["lin"].data_ptr(), n_rays, R.M, ns, R.sample_depth, R.dists_scale,
+                                     buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
+                                     buf["rayflag"].data_ptr(), _stream(R.dev))
+    capi.check(rc, "sdn_field_encode")
+    return buf
+
+
+def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns):
+    """net_out [R,64] for intersections vid [R,M] / d2 [2,R,M] / raydirs rd [R,3]."""
+    st = R._fused_style or prepare_style(R)
+    vid, d2, rd, sky_c = vid.contiguous(), d2.contiguous(), rd.contiguous(), sky_c.contiguous()
+    n_rays = vid.shape[0]
+    buf = encode(R, vid, d2, rd, cam_ori, ns)
+    st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
+    net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
+    with torch.cuda.device(R.dev):
+        rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
+                                  buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
+                                  sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, 0, _stream(R.dev))
+    capi.check(rc, "sdn_field_mlp")
+    return net_out
+
+
+def time_encode_kernel(R, vid, d2, rd, cam_ori, ns, reps=5):
+    """(samples per launch, avg ms, algorithmic bytes per sample, kernel name) for the roofline record."""
+    from .renderer import _time_ms
+    n = vid.numel() // R.M
+    vid, d2, rd = vid.reshape(n, R.M).contiguous(), d2.reshape(2, n, R.M).contiguous(), rd.reshape(n, 3).contiguous()
+    buf = _buffers(R, n, ns)
+    ms = _time_ms(lambda: encode(R, vid, d2, rd, cam_ori, ns, buf), reps)
+    return n * ns, ms, 16404, "encode_kernel (collapsed 3-D table: 4096 B/sample actually gathered)"

@@ -1,0 +1,124 @@
+"""Building blocks of the fused field path on the MI355X: MFMA operand layouts, table collapse, encode."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mfma_layout_probe():
+    """A[32,16] x B[16,32] through v_mfma_f32_32x32x16_f16 with the lane/register maps field.hip assumes.
+    Asymmetric integer data so that any row/column or k permutation error shows up."""
+    from scenedreamer_amd import capi
+    lib = capi.lib()
+    rng = np.random.default_rng(0)
+    A = rng.integers(-8, 9, size=(32, 16)).astype(np.float32)
+    B = rng.integers(-8, 9, size=(16, 32)).astype(np.float32)
+    A[3, :] = 0.0
+    A[3, 5] = 2.0 ** -20      # f16 subnormal input must not be flushed (the lo parts of the split live there)
+    B[5, 7] = 1024.0
+    a, b = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+    c = torch.zeros(32, 32, device="cuda")
+    capi.check(lib.sdn_debug_mfma_probe(a.data_ptr(), b.data_ptr(), c.data_ptr(), capi.current_stream()))
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    np.testing.assert_allclose(c.cpu().numpy(), ref, rtol=0, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def renderer(weights_full, scene256):
+    from scenedreamer_amd import synth
+    from scenedreamer_amd.renderer import Renderer
+    r = Renderer(weights_full, scene256, "cuda")
+    r.set_style(synth.make_style(8888))
+    return r
+
+
+def test_collapsed_table_equals_5d_lookup(renderer, oracle, weights_full):
+    """Features from the per-scene collapsed 3-D table == the reference's 32-corner 5-D blend (oracle)."""
+    from scenedreamer_amd import fused
+    sc = fused.prepare_scene(renderer)
+    T = sc["T"]
+    rng = np.random.default_rng(1)
+    B = 4096
+    x3 = rng.random((B, 3), dtype=np.float32)
+    genc01 = ((sc["genc"] + 1) / 2).astype(np.float32)
+    x5 = np.concatenate([x3, np.broadcast_to(genc01, (B, 2))], axis=1).astype(np.float32)
+    S = np.float32(renderer.grid_S)
+    ref = oracle.grid_encode_fwd(x5, weights_full["hash_encoder.embeddings"], weights_full["hash_encoder.offsets"], S, 16)
+    table = sc["table3"].cpu().numpy()          # [16, T, 8]
+    scales = sc["scales"].cpu().numpy()
+    P1, P2 = np.uint32(2654435761), np.uint32(805459861)
+    got = np.zeros_like(ref)
+    for l in range(16):
+        pos = (x3 * scales[l]).astype(np.float32) + np.float32(0.5)
+        pg = np.floor(pos).astype(np.uint32)
+        fr = (pos - pg).astype(np.float32)
+        acc = np.zeros((B, 8), np.float32)
+        for c in range(8):
+            cb = [(c >> d) & 1 for d in range(3)]
+            w = np.ones(B, np.float32)
+            for d in range(3):
+                w = w * (fr[:, d] if cb[d] else (np.float32(1) - fr[:, d]))
+            with np.errstate(over="ignore"):
+                h = (pg[:, 0] + np.uint32(cb[0])) ^ ((pg[:, 1] + np.uint32(cb[1])) * P1) ^ ((pg[:, 2] + np.uint32(cb[2])) * P2)
+            acc += w[:, None] * table[l][h & np.uint32(T - 1)]
+        got[l] = acc
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_encode_matches_oracle(renderer, oracle, weights_full, lut, tag):
+    """Sample placement (discrete decisions bit-exact) and features of encode_kernel vs the CPU oracle."""
+    from oracle import field_ref as FR
+    from scenedreamer_amd import fused
+    g = golden(f"field_{tag}.npz")
+    renderer.set_style_code(g["z"])
+    renderer.global_enc = torch.from_numpy(g["global_enc"]).cuda()
+    renderer._fused_scene = None
+    M = g["voxel_id"].shape[-2]
+    ns = int(g["num_samples"])
+    vid = torch.from_numpy(g["voxel_id"]).cuda().reshape(-1, M)
+    d2 = torch.from_numpy(g["depth2"]).cuda().reshape(2, -1, M)
+    rd = torch.from_numpy(g["raydirs"]).cuda().reshape(-1, 3)
+    R = vid.shape[0]
+    buf = fused.encode(renderer, vid, d2, rd, torch.from_numpy(g["cam_ori"]), ns)
+    torch.cuda.synchronize()
+    _, aux = FR.forward_perpix(weights_full, lut, renderer.voxel_t.shape, g["voxel_id"], g["depth2"], g["raydirs"],
+                               g["cam_ori"][None], g["z"], g["global_enc"], ns, sky_avg=g["sky_avg"], return_aux=True)
+    nch = (ns + 3) // 4
+    ntile = (R + 7) // 8
+    feat = buf["feat"].cpu().numpy().reshape(ntile, nch, 8, 64, 8)
+    dist = buf["dist"].cpu().numpy().reshape(ntile, nch, 32)
+    label = buf["label"].cpu().numpy().reshape(ntile, nch, 32)
+    # un-permute: lane = h*32 + 4*ray_in_tile + sample_in_step ; level = 2*s + h
+    ref_feat = aux["feature_in"].numpy().reshape(R, ns, 16, 8)
+    ref_dist = (aux["new_dists"].numpy().reshape(R, ns) * np.float32(0.25)).astype(np.float32)
+    ref_idx = aux["new_idx"].numpy().reshape(R, ns)
+    lutt = np.asarray(lut)
+    red = lutt[g["voxel_id"].reshape(R, M)]
+    red[red == 0] = 3
+    ref_label = np.take_along_axis(red, ref_idx, axis=1)
+    got_feat = np.zeros_like(ref_feat)
+    got_dist = np.zeros_like(ref_dist)
+    got_label = np.zeros_like(ref_label)
+    for ray in range(R):
+        t, rt = divmod(ray, 8)
+        for smp in range(ns):
+            ch, si = divmod(smp, 4)
+            j = 4 * rt + si
+            got_dist[ray, smp] = dist[t, ch, j]
+            got_label[ray, smp] = label[t, ch, j]
+            for h in range(2):
+                got_feat[ray, smp, h::2] = feat[t, ch, :, h * 32 + j, :]
+    np.testing.assert_array_equal(got_label, ref_label)
+    np.testing.assert_array_equal(got_dist.view(np.int32), ref_dist.view(np.int32))
+    np.testing.assert_allclose(got_feat, ref_feat, rtol=0, atol=5e-6)
+    # ray flags
+    flags = buf["rayflag"].cpu().numpy()
+    sky_only = g["voxel_id"].reshape(R, M)[:, 0] == 0
+    np.testing.assert_array_equal((flags & 1).astype(bool), sky_only)
+    wc = aux["worldcoord2"].numpy().reshape(R, ns, 3)
+    nosky = (g["voxel_id"].reshape(R, M)[:, -1] != 0) | (wc[:, :, 0] <= 1.0).any(axis=1)
+    np.testing.assert_array_equal(((flags >> 1) & 1).astype(bool), nosky)
