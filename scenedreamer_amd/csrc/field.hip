@@ -35,6 +35,8 @@
 //                     epilogues on the VALU.
 #include <hip/hip_fp16.h>
 
+#include <cstdlib>
+
 #include "sdn_common.h"
 
 namespace {
@@ -101,6 +103,7 @@ struct MlpParams {
     const float *sky_c;        // [R, 64] sky_net output per ray
     float *net_out;            // [R, 64]
     int32_t R, ns, nch, n_tiles;
+    int32_t dbg;               // timing experiments only: bit0 skip ring DMA, bit1 skip ring barriers, bit2 skip MFMAs
 };
 
 // =====================================================================================================
@@ -591,6 +594,254 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
 }
 
 // =====================================================================================================
+// MLP + compositing, weights staged through LDS  (the shipping variant)
+// =====================================================================================================
+// v0 above fetches every A fragment per wave straight from L2: 4 waves x 4 KiB per 192 matrix-pipe cycles =
+// 85 B/clk/CU through a vector-memory path that delivers 64 B/clk/CU at best -- it is L1/TA-bound (measured
+// 40.8 % MFMA busy).  Here the 4 waves of a workgroup share ONE copy of the weight stream in LDS:
+//   * the packed weights (1.47 MB per pass, identical for every pass) flow L2 -> LDS by LDS-DMA
+//     (global_load_lds, 16 B/lane, no VGPRs) into a ring of 8 slots x 16 KiB; a slot is one k-step of all 8
+//     row blocks, hi+lo (or 4 k-steps of the 2-row-block output layer); every wave issues 4 of a slot's 16
+//     1-KiB pieces, 7 slots ahead of consumption;
+//   * per slot: counted s_waitcnt vmcnt(20) (this wave's pieces of slots g and g+1 have landed) -> raw s_barrier
+//     (everybody's have, and everybody is done with slot g-1) -> issue the DMA for slot g+7 into the position of
+//     slot g-1 -> ds_read_b128 fragments (lane-linear image = conflict-free) + 24 MFMAs.  Because slot g+1 is
+//     complete at the barrier of slot g, the 4-deep register ring of fragment reads runs across slot boundaries;
+//   * LDS traffic 16 KiB/slot/wave -> 85 B/clk/CU of 256; L2 -> LDS 16 KiB per slot per CU = 21 B/clk/CU.
+// All small per-style constants (biases, density head) live in LDS as well so that no ordinary global load is
+// in flight inside the layer loops (hipcc drains vmcnt to 0 -- and with it the DMA ring -- before it lets an
+// ordinary load's result be used).
+constexpr int NSLOT = 8;
+constexpr int SLOT_BYTES = 16384;
+constexpr int DMA_AHEAD = 7;
+constexpr int SLOTS_PER_PASS = 8 + 5 * 16 + 4;   // 92
+constexpr int LDS_RING = 0;
+constexpr int LDS_CONST = NSLOT * SLOT_BYTES;     // fp32 constant block
+constexpr int LDS_FLAGS = LDS_CONST + ((C_TOTAL * 4 + 255) / 256) * 256;
+constexpr int LDS_TOTAL = LDS_FLAGS + 64;
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) const char glb_char;
+
+struct Ring {
+    int dbg;
+    const char *wbytes;   // packed weights
+    int g;                // slots consumed so far (uniform across the workgroup)
+    int next_in_pass;     // slot-in-pass index of slot g + DMA_AHEAD
+    int wave, lane;
+};
+
+__device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_global, int slot_in_pass) {
+    const int pos = slot_global & (NSLOT - 1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int piece = r.wave * 4 + i;
+        const char *src = r.wbytes + (size_t)slot_in_pass * SLOT_BYTES + piece * 1024 + r.lane * 16;
+        char *dst = lds + LDS_RING + pos * SLOT_BYTES + piece * 1024;  // wave-uniform; hardware adds lane*16
+        __builtin_amdgcn_global_load_lds((glb_char *)src, (lds_char *)dst, 16, 0, 0);
+    }
+}
+
+// make slot r.g (and r.g+1) readable for everybody, free slot r.g-1, refill it
+__device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_AHEAD - 2) * 4) : "memory");
+    if (!(r.dbg & 2)) __builtin_amdgcn_s_barrier();
+    if (!(r.dbg & 1)) ring_issue(lds, r, r.g + DMA_AHEAD, r.next_in_pass);
+    r.next_in_pass = r.next_in_pass + 1 == SLOTS_PER_PASS ? 0 : r.next_in_pass + 1;
+    const int pos = r.g & (NSLOT - 1);
+    r.g++;
+    return pos;
+}
+
+template <int NIB>
+__device__ __forceinline__ void lds_unit(const char *lds, int pos, int u_in_slot, int lane, half8 (&a)[4]) {
+    // unit = two row blocks of one k-step: fragments (ib,hi) (ib,lo) (ib+1,hi) (ib+1,lo), 1 KiB each, contiguous
+    const char *q = lds + LDS_RING + pos * SLOT_BYTES + u_in_slot * 4096 + lane * 16;
+    a[0] = *reinterpret_cast<const half8 *>(q);
+    a[1] = *reinterpret_cast<const half8 *>(q + 1024);
+    a[2] = *reinterpret_cast<const half8 *>(q + 2048);
+    a[3] = *reinterpret_cast<const half8 *>(q + 3072);
+}
+
+// One dense layer from the LDS ring.  Units are numbered across the whole layer; 4 units per slot in both
+// layer shapes (NIB=8: one k-step; NIB=2: four k-steps).
+template <int NIB, int NSTEPS>
+__device__ __forceinline__ void gemm_layer_lds(char *lds, Ring &r, const half8 (&bh)[16], const half8 (&bl)[16],
+                                               f32x16 (&acc)[NIB]) {
+    constexpr int PAIRS = NIB / 2, UNITS = NSTEPS * PAIRS, RD = 4, UPS = 4;  // units per slot
+    static_assert(UNITS % UPS == 0, "layer must be a whole number of slots");
+    half8 ring[RD][4];
+    int pos_cur = ring_acquire(lds, r);   // slot of unit 0; the next slot is complete as well
+    int pos_nxt = (pos_cur + 1) & (NSLOT - 1);
+#pragma unroll
+    for (int u = 0; u < RD - 1; u++) lds_unit<NIB>(lds, pos_cur, u, r.lane, ring[u]);
+#pragma unroll
+    for (int u = 0; u < UNITS; u++) {
+        if (u % UPS == 0 && u != 0) {  // entering a new slot: acquire it (also completes the one after it)
+            pos_cur = ring_acquire(lds, r);
+            pos_nxt = (pos_cur + 1) & (NSLOT - 1);
+        }
+        const int un = u + RD - 1;       // unit to prefetch into registers
+        if (un < UNITS) {
+            const bool same_slot = (un / UPS) == (u / UPS);
+            lds_unit<NIB>(lds, same_slot ? pos_cur : pos_nxt, un % UPS, r.lane, ring[un % RD]);
+        }
+        const int s = u / PAIRS, ib = 2 * (u % PAIRS);
+        half8(&a)[4] = ring[u % RD];
+        if (!(r.dbg & 4)) {
+            acc[ib] = mfma16(a[0], bh[s], acc[ib]);
+            acc[ib + 1] = mfma16(a[2], bh[s], acc[ib + 1]);
+            acc[ib] = mfma16(a[1], bh[s], acc[ib]);
+            acc[ib + 1] = mfma16(a[3], bh[s], acc[ib + 1]);
+            acc[ib] = mfma16(a[0], bl[s], acc[ib]);
+            acc[ib + 1] = mfma16(a[2], bl[s], acc[ib + 1]);
+        } else {
+            asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_kernel_lds(const MlpParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int q = j & 3;
+
+    // constants -> LDS
+    float *cst = reinterpret_cast<float *>(lds + LDS_CONST);
+    for (int i = threadIdx.x; i < C_TOTAL; i += 256) cst[i] = p.consts[i];
+    __syncthreads();
+
+    Ring r;
+    r.dbg = p.dbg;
+    r.wbytes = reinterpret_cast<const char *>(p.wpk);
+    r.g = 0;
+    r.wave = wave;
+    r.lane = lane;
+    // prologue: slots 0 .. DMA_AHEAD-1 of the first pass
+#pragma unroll
+    for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
+    r.next_in_pass = DMA_AHEAD;
+
+    const int n_groups = (p.n_tiles + 3) >> 2;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int tile = grp * 4 + wave;
+        const bool tile_ok = tile < p.n_tiles;
+        const int ray = tile * RAYS_PER_TILE + (j >> 2);
+        const bool ray_ok = tile_ok && ray < p.R;
+        const uint8_t flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
+        const bool any_hit = __any(!(flag & 1));
+        // workgroup-uniform decision: skip the group when none of its 32 rays hits anything
+        volatile int *flags = reinterpret_cast<volatile int *>(lds + LDS_FLAGS);
+        if (lane == 0) flags[wave] = any_hit ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool grp_hit = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // flags may be rewritten by the next group only after everyone read them
+
+        float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float carry = 0.f, tsum = 0.f;
+
+        for (int ch = 0; grp_hit && ch < p.nch; ch++) {
+            const size_t tc = (size_t)(tile_ok ? tile : 0) * p.nch + ch;
+            half8 bh[16], bl[16];
+            f32x16 acc[8];
+            const float *fin = p.feat + (tc * 8 * 64 + lane) * 8;
+            const int lab = p.label[tc * 32 + j];
+            const float dist = tile_ok ? p.dist[tc * 32 + j] : 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const float4 a = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8);
+                const float4 b = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8 + 4);
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                split8(v, bh[s], bl[s]);
+            }
+            // ---- fc_1 ------------------------------------------------------------------------------
+            zero_acc<8>(acc);
+            gemm_layer_lds<8, 8>(lds, r, bh, bl, acc);
+            activate(acc, cst + C_LABEL_BIAS + lab * HID, h, bh, bl);
+            // ---- fc_2 .. fc_6 ----------------------------------------------------------------------
+            float sigma = 0.f;
+#pragma unroll 1
+            for (int l = 0; l < 5; l++) {
+                zero_acc<8>(acc);
+                gemm_layer_lds<8, 16>(lds, r, bh, bl, acc);
+                activate(acc, cst + C_BETA + l * HID, h, bh, bl);
+                if (l == 2) {  // density head on the fp32 activations of fc_4 (layers.py:114)
+                    float part = 0.f;
+#pragma unroll
+                    for (int ib = 0; ib < 8; ib++) {
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; g4++) {
+                            const float4 w = *reinterpret_cast<const float4 *>(cst + C_WSIGMA + 32 * ib + 8 * g4 + 4 * h);
+                            part += w.x * acc[ib][4 * g4] + w.y * acc[ib][4 * g4 + 1] + w.z * acc[ib][4 * g4 + 2] +
+                                    w.w * acc[ib][4 * g4 + 3];
+                        }
+                    }
+                    sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
+                }
+            }
+            // ---- fc_out_c ----------------------------------------------------------------------------
+            f32x16 col[2];
+            load_rowvec<2>(cst + C_BC, h, col);
+            gemm_layer_lds<2, 16>(lds, r, bh, bl, col);
+            // ---- volume rendering (mc_utils.py:154-161) ---------------------------------------------------
+            const float fe = fmaxf(sigma, 0.f) * dist;
+            float incl = fe;
+            float up = __shfl_up(incl, 1, 4);
+            if (q >= 1) incl += up;
+            up = __shfl_up(incl, 2, 4);
+            if (q >= 2) incl += up;
+            float ex = __shfl_up(incl, 1, 4);
+            if (q == 0) ex = 0.f;
+            const float excl = carry + ex;
+            const float wgt = (1.f - __expf(-fe)) * __expf(-excl);
+            carry += __shfl(incl, 3, 4);
+            tsum += wgt;
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                for (int rr = 0; rr < 16; rr++) {
+                    const float rgb = fminf(fmaxf(col[ib][rr], -1.f), 1.f) + 1.f;  // scenedreamer.py:408
+                    float v = wgt * rgb;
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    if ((rr >> 2) == q) outq[ib][rr & 3] += v;
+                }
+        }
+
+        // ---- blend the sky, store ---------------------------------------------------------------------
+        tsum += __shfl_xor(tsum, 1);
+        tsum += __shfl_xor(tsum, 2);
+        const bool sky_only = flag & 1, nosky = flag & 2;
+        if (sky_only) tsum = 0.f;  // scenedreamer.py:376
+        const float sky_w = 1.f - tsum;
+        if (ray_ok) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++) {
+                const int f0 = 32 * ib + 8 * q + 4 * h;
+                const float4 sc = *reinterpret_cast<const float4 *>(p.sky_c + (size_t)ray * OUTC + f0);
+                const float4 sa = *reinterpret_cast<const float4 *>(cst + C_SKY_AVG + f0);
+                const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sav[4] = {sa.x, sa.y, sa.z, sa.w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float sky = nosky ? (scv[e] * 0.f + sav[e]) : scv[e];          // :401, mask in {0,1}
+                    const float rgb_sky = fminf(fmaxf(sky, -1.f), 1.f) + 1.f;
+                    o[e] = (sky_only ? 0.f : outq[ib][e]) + sky_w * rgb_sky - 1.f;       // :410-413
+                }
+                *reinterpret_cast<float4 *>(p.net_out + (size_t)ray * OUTC + f0) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    // the ring runs DMA_AHEAD slots ahead of the last pass: let it land before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// =====================================================================================================
 // debug probe: checks the MFMA operand layouts this file relies on (tests/test_fused_gpu.py)
 // =====================================================================================================
 __global__ void mfma_probe_kernel(const float *A, const float *B, float *C) {
@@ -745,10 +996,25 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     p.R = n_rays; p.ns = num_samples;
     p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
     p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
+    {
+        const char *e = getenv("SDN_MLP_DBG");
+        p.dbg = e ? atoi(e) : 0;
+    }
     int wg = n_workgroups > 0 ? n_workgroups : 256;
     const int need = sdn::div_up(p.n_tiles, 4);
     if (wg > need) wg = need;
-    hipLaunchKernelGGL(mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    static const int variant = [] {
+        const char *e = getenv("SDN_MLP_VARIANT");   // "l2": v0 (weights straight from L2), default: LDS ring
+        return (e && e[0] == 'l' && e[1] == '2') ? 0 : 1;
+    }();
+    if (variant == 0) {
+        hipLaunchKernelGGL(mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        const int groups = sdn::div_up(p.n_tiles, 4);
+        int wgl = n_workgroups > 0 ? n_workgroups : 256;
+        if (wgl > groups) wgl = groups;
+        hipLaunchKernelGGL(mlp_kernel_lds, dim3(wgl), dim3(256), 0, (hipStream_t)stream, p);
+    }
     return sdn::check_launch("sdn_field_mlp");
 }
 
