@@ -36,6 +36,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
+#include <utility>
 
 #include "sdn_common.h"
 
@@ -59,7 +60,7 @@ constexpr int MAX_LIN = 80;     // up to 78 samples per ray
 // layer 0: fc_1   K=128 -> 8 k-steps, 8 row blocks
 // layer 1..5: fc_2..fc_6  K=256 -> 16 k-steps, 8 row blocks
 // layer 6: fc_out_c  K=256 -> 16 k-steps, 2 row blocks
-// fragment (s, ib, p) of a layer sits at ((s * nib + ib) * 2 + p) * 64 + lane,  p = 0 hi / 1 lo
+// fragment f of unit u of a layer sits at (u * 4 + f) * 64 + lane (unit order: see unit_coords)
 constexpr size_t L0_FRAGS = 8 * 8 * 2 * 64;
 constexpr size_t LH_FRAGS = 16 * 8 * 2 * 64;
 constexpr size_t LO_FRAGS = 16 * 2 * 2 * 64;
@@ -103,7 +104,6 @@ struct MlpParams {
     const float *sky_c;        // [R, 64] sky_net output per ray
     float *net_out;            // [R, 64]
     int32_t R, ns, nch, n_tiles;
-    int32_t dbg;               // timing experiments only: bit0 skip ring DMA, bit1 skip ring barriers, bit2 skip MFMAs
 };
 
 // =====================================================================================================
@@ -148,6 +148,23 @@ __host__ __device__ inline int kmap_hidden(int s, int h, int e) {
     return 32 * (s >> 1) + 16 * (s & 1) + (e & 3) + 8 * (e >> 2) + 4 * h;
 }
 
+// Unit order of the packed stream.  A unit = the 4 fragments (ib,hi) (ib,lo) (ib+1,hi) (ib+1,lo) of one k-step
+// for a pair of 32-row output blocks, 4 KiB; 4 consecutive units form one 16-KiB LDS ring slot.
+//   8-row-block layers: the UPPER half of the outputs (row blocks 0-3) for all k-steps comes first, then the
+//   lower half (4-7): unit u -> half = u / (2*NS), s = (u % (2*NS)) / 2, ib = 4*half + 2*(u & 1).
+//   This order is what lets mlp_kernel hide every activation epilogue behind MFMAs (see there).
+//   output layer (2 row blocks): unit u = k-step u.
+__host__ __device__ inline void unit_coords(int nib, int ns, int u, int &s, int &ib0) {
+    if (nib == 8) {
+        const int half = u / (2 * ns), rem = u % (2 * ns);
+        s = rem >> 1;
+        ib0 = 4 * half + 2 * (rem & 1);
+    } else {
+        s = u;
+        ib0 = 0;
+    }
+}
+
 struct PackParams {
     const float *w1;      // [256,128]
     const float *wh[5];   // [256,256] each, W * alpha already folded
@@ -156,24 +173,26 @@ struct PackParams {
 };
 
 __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (layer, s, ib, lane)
-    const size_t n0 = 8 * 8 * 64, nh = 16 * 8 * 64, no = 16 * 2 * 64;
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;  // one thread per (layer, unit, row block of the pair, lane)
+    const size_t n0 = 32 * 2 * 64, nh = 64 * 2 * 64, no = 16 * 2 * 64;
     if (g >= n0 + 5 * nh + no) return;
-    int layer, s, ib, lane, nib, K;
+    int layer, nib, ns, K;
     const float *W;
     size_t base, r = g;
     if (r < n0) {
-        layer = 0; nib = 8; K = FEAT; W = p.w1; base = 0;
+        layer = 0; nib = 8; ns = 8; K = FEAT; W = p.w1; base = 0;
     } else if (r < n0 + 5 * nh) {
-        r -= n0; layer = 1 + (int)(r / nh); r %= nh; nib = 8; K = HID; W = p.wh[layer - 1];
+        r -= n0; layer = 1 + (int)(r / nh); r %= nh; nib = 8; ns = 16; K = HID; W = p.wh[layer - 1];
         base = L0_FRAGS + (size_t)(layer - 1) * LH_FRAGS;
     } else {
-        r -= n0 + 5 * nh; layer = 6; nib = 2; K = HID; W = p.wc; base = L0_FRAGS + 5 * LH_FRAGS;
+        r -= n0 + 5 * nh; layer = 6; nib = 2; ns = 16; K = HID; W = p.wc; base = L0_FRAGS + 5 * LH_FRAGS;
     }
-    lane = (int)(r % 64); r /= 64;
-    ib = (int)(r % nib);
-    s = (int)(r / nib);
-    const int row = 32 * ib + (lane & 31), h = lane >> 5;
+    const int lane = (int)(r % 64); r /= 64;
+    const int sel = (int)(r % 2);
+    const int u = (int)(r / 2);
+    int s, ib0;
+    unit_coords(nib, ns, u, s, ib0);
+    const int row = 32 * (ib0 + sel) + (lane & 31), h = lane >> 5;
     half8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -183,8 +202,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
         hi[e] = vh;
         lo[e] = (_Float16)(v - (float)vh);
     }
-    p.out[base + ((size_t)(s * nib + ib) * 2 + 0) * 64 + lane] = hi;
-    p.out[base + ((size_t)(s * nib + ib) * 2 + 1) * 64 + lane] = lo;
+    p.out[base + ((size_t)u * 4 + 2 * sel + 0) * 64 + lane] = hi;
+    p.out[base + ((size_t)u * 4 + 2 * sel + 1) * 64 + lane] = lo;
 }
 
 // =====================================================================================================
@@ -367,250 +386,26 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
 // =====================================================================================================
 // MLP + compositing
 // =====================================================================================================
-__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.2f * v; }
-
-__device__ __forceinline__ void split8(const float (&v)[8], half8 &hi, half8 &lo) {
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const _Float16 x = (_Float16)v[e];
-        hi[e] = x;
-        lo[e] = (_Float16)(v[e] - (float)x);
-    }
-}
-
-// acc[ib][r] = vec[32*ib + (r&3) + 8*(r>>2) + 4*h] : the per-lane view of a 256 (or 64) vector
-template <int NIB>
-__device__ __forceinline__ void load_rowvec(const float *__restrict__ vec, int h, f32x16 (&acc)[NIB]) {
-#pragma unroll
-    for (int ib = 0; ib < NIB; ib++) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 v = *reinterpret_cast<const float4 *>(vec + 32 * ib + 8 * g + 4 * h);
-            acc[ib][4 * g + 0] = v.x; acc[ib][4 * g + 1] = v.y; acc[ib][4 * g + 2] = v.z; acc[ib][4 * g + 3] = v.w;
-        }
-    }
-}
-
-// One dense layer, transposed: acc[ib] += W[32 ib.., k-step s] * X[k-step s, 32 samples], 3-term f16 split.
-// Work is cut into "units" of two row blocks of one k-step (4 A fragments, 6 MFMAs = 192 matrix-pipe cycles).
-// A 4-deep register ring keeps 3 units of fragment loads (12 x 1 KiB per wave) in flight ahead of the MFMAs,
-// i.e. ~580 cycles of cover for the L2 round trip; sched_barrier pins that distance (left alone, the compiler
-// front-loads a whole layer and spills a thousand registers).
-// Fragment fetch through a buffer descriptor: the address is {SGPR base, one VGPR lane offset, scalar offset}.
-// With flat pointers the compiler materialises (and then spills) one 64-bit VGPR address per fragment.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ half8 load_frag(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int byte_off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, byte_off, 0);
-    return __builtin_bit_cast(half8, v);
-}
-
-template <int NIB>
-__device__ __forceinline__ void load_unit(__amdgpu_buffer_rsrc_t rsrc, int u, int lane_off, half8 (&a)[4]) {
-    constexpr int PAIRS = NIB / 2;
-    const int s = u / PAIRS, ib = 2 * (u % PAIRS);
-    const int base = ((s * NIB + ib) * 2) * 1024;  // bytes; fragment (s, ib, p) is 1 KiB
-    a[0] = load_frag(rsrc, lane_off, base);          // hi, row block ib
-    a[1] = load_frag(rsrc, lane_off, base + 1024);   // lo, row block ib
-    a[2] = load_frag(rsrc, lane_off, base + 2048);   // hi, row block ib+1
-    a[3] = load_frag(rsrc, lane_off, base + 3072);   // lo, row block ib+1
-}
-
-template <int NIB, int NSTEPS>
-__device__ __forceinline__ void gemm_layer(const half8 *wp, int lane, const half8 (&bh)[16],
-                                           const half8 (&bl)[16], f32x16 (&acc)[NIB]) {
-    constexpr int PAIRS = NIB / 2, UNITS = NSTEPS * PAIRS, RD = 4;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<half8 *>(wp), 0, NSTEPS * NIB * 2 * 1024, 0x00020000);
-    const int lane_off = lane * 16;
-    half8 ring[RD][4];
-#pragma unroll
-    for (int u = 0; u < RD - 1; u++) load_unit<NIB>(rsrc, u, lane_off, ring[u]);
-#pragma unroll
-    for (int u = 0; u < UNITS; u++) {
-        if (u + RD - 1 < UNITS) load_unit<NIB>(rsrc, u + RD - 1, lane_off, ring[(u + RD - 1) % RD]);
-        const int s = u / PAIRS, ib = 2 * (u % PAIRS);
-        half8(&a)[4] = ring[u % RD];
-        acc[ib] = mfma16(a[0], bh[s], acc[ib]);
-        acc[ib + 1] = mfma16(a[2], bh[s], acc[ib + 1]);
-        acc[ib] = mfma16(a[1], bh[s], acc[ib]);
-        acc[ib + 1] = mfma16(a[3], bh[s], acc[ib + 1]);
-        acc[ib] = mfma16(a[0], bl[s], acc[ib]);
-        acc[ib + 1] = mfma16(a[2], bl[s], acc[ib + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Bias + activation + re-split of a finished layer: the C/D registers become the next layer's B fragments.
-// bias is the per-output-feature vector (beta of the ModLinear, or the label-bias row for fc_1); it is fetched
-// in 8-float pieces right where it is consumed so that it never occupies registers next to the accumulators.
-__device__ __forceinline__ void activate(f32x16 (&acc)[8], const float *__restrict__ bias, int h, half8 (&bh)[16],
-                                         half8 (&bl)[16]) {
-#pragma unroll
-    for (int ib = 0; ib < 8; ib++) {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const float4 b0 = *reinterpret_cast<const float4 *>(bias + 32 * ib + 16 * q + 4 * h);
-            const float4 b1 = *reinterpret_cast<const float4 *>(bias + 32 * ib + 16 * q + 8 + 4 * h);
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; e++) {
-                v[e] = lrelu(acc[ib][8 * q + e] + bb[e]);
-                acc[ib][8 * q + e] = v[e];
-            }
-            split8(v, bh[2 * ib + q], bl[2 * ib + q]);
-        }
-    }
-}
-
-template <int NIB>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NIB]) {
-#pragma unroll
-    for (int ib = 0; ib < NIB; ib++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[ib][r] = 0.f;
-}
-
-__global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int h = lane >> 5, j = lane & 31;
-    const float *cst = p.consts;
-
-    for (int tile = blockIdx.x * 4 + wave; tile < p.n_tiles; tile += gridDim.x * 4) {
-        const int ray = tile * RAYS_PER_TILE + (j >> 2);
-        const bool ray_ok = ray < p.R;
-        const uint8_t flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
-        // wave-uniform: nothing to integrate when none of the 8 rays hits anything
-        const bool any_hit = __any(!(flag & 1));
-
-        // lane (ray, q = j&3, h) ends up owning output features 32*ib + 8*q + 4*h + {0..3}, ib = 0,1
-        float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        const int q = j & 3;
-        float carry = 0.f, tsum = 0.f;
-
-        for (int ch = 0; any_hit && ch < p.nch; ch++) {
-            const size_t tc = (size_t)tile * p.nch + ch;
-            half8 bh[16], bl[16];
-            f32x16 acc[8];
-            // ---- layer fc_1: features (B) and label bias (C init) ----------------------------------
-            {
-                const float *fin = p.feat + (tc * 8 * 64 + lane) * 8;
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const float4 a = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8);
-                    const float4 b = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8 + 4);
-                    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                    split8(v, bh[s], bl[s]);
-                }
-                const int lab = p.label[tc * 32 + j];
-                zero_acc<8>(acc);
-                gemm_layer<8, 8>(p.wpk, lane, bh, bl, acc);
-                activate(acc, cst + C_LABEL_BIAS + lab * HID, h, bh, bl);
-            }
-            // ---- fc_2 .. fc_6 ----------------------------------------------------------------------
-            float sigma = 0.f;
-#pragma unroll 1
-            for (int l = 0; l < 5; l++) {
-                zero_acc<8>(acc);
-                gemm_layer<8, 16>(p.wpk + L0_FRAGS + (size_t)l * LH_FRAGS, lane, bh, bl, acc);
-                activate(acc, cst + C_BETA + l * HID, h, bh, bl);
-                if (l == 2) {  // density head on the fp32 activations of fc_4 (layers.py:114)
-                    float part = 0.f;
-#pragma unroll
-                    for (int ib = 0; ib < 8; ib++) {
-#pragma unroll
-                        for (int g = 0; g < 4; g++) {
-                            const float4 w = *reinterpret_cast<const float4 *>(cst + C_WSIGMA + 32 * ib + 8 * g + 4 * h);
-                            part += w.x * acc[ib][4 * g] + w.y * acc[ib][4 * g + 1] + w.z * acc[ib][4 * g + 2] +
-                                    w.w * acc[ib][4 * g + 3];
-                        }
-                    }
-                    sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
-                }
-            }
-            // ---- fc_out_c ----------------------------------------------------------------------------
-            f32x16 col[2];
-            load_rowvec<2>(cst + C_BC, h, col);
-            gemm_layer<2, 16>(p.wpk + L0_FRAGS + 5 * LH_FRAGS, lane, bh, bl, col);
-            // ---- volume rendering (mc_utils.py:154-161) over the 4 samples of each ray in this step ----
-            const float fe = fmaxf(sigma, 0.f) * p.dist[tc * 32 + j];
-            // exclusive prefix within the quad (samples are lanes j&3 = 0..3 in ray order)
-            float incl = fe;
-            float up = __shfl_up(incl, 1, 4);
-            if ((j & 3) >= 1) incl += up;
-            up = __shfl_up(incl, 2, 4);
-            if ((j & 3) >= 2) incl += up;
-            float ex = __shfl_up(incl, 1, 4);
-            if ((j & 3) == 0) ex = 0.f;
-            const float excl = carry + ex;
-            const float wgt = (1.f - __expf(-fe)) * __expf(-excl);
-            carry += __shfl(incl, 3, 4);
-            tsum += wgt;
-#pragma unroll
-            for (int ib = 0; ib < 2; ib++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float rgb = fminf(fmaxf(col[ib][r], -1.f), 1.f) + 1.f;  // scenedreamer.py:408
-                    float v = wgt * rgb;
-                    v += __shfl_xor(v, 1);   // sum over the 4 samples of the ray held by this quad
-                    v += __shfl_xor(v, 2);
-                    if ((r >> 2) == q) outq[ib][r & 3] += v;
-                }
-        }
-
-        // ---- reduce the ray's 4 lanes, blend the sky, store -------------------------------------------
-        tsum += __shfl_xor(tsum, 1);
-        tsum += __shfl_xor(tsum, 2);
-        const bool sky_only = flag & 1, nosky = flag & 2;
-        if (sky_only) tsum = 0.f;  // scenedreamer.py:376
-        const float sky_w = 1.f - tsum;
-        if (ray_ok) {
-#pragma unroll
-            for (int ib = 0; ib < 2; ib++) {
-                {
-                    {
-                        const int f0 = 32 * ib + 8 * q + 4 * h;
-                        const float4 sc = *reinterpret_cast<const float4 *>(p.sky_c + (size_t)ray * OUTC + f0);
-                        const float4 sa = *reinterpret_cast<const float4 *>(cst + C_SKY_AVG + f0);
-                        float o[4];
-                        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sav[4] = {sa.x, sa.y, sa.z, sa.w};
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const float sky = nosky ? (scv[e] * 0.f + sav[e]) : scv[e];  // :401 with mask in {0,1}
-                            const float rgb_sky = fminf(fmaxf(sky, -1.f), 1.f) + 1.f;
-                            o[e] = (sky_only ? 0.f : outq[ib][e]) + sky_w * rgb_sky - 1.f;  // :410-413
-                        }
-                        *reinterpret_cast<float4 *>(p.net_out + (size_t)ray * OUTC + f0) = make_float4(o[0], o[1], o[2], o[3]);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// =====================================================================================================
-// MLP + compositing, weights staged through LDS  (the shipping variant)
-// =====================================================================================================
-// v0 above fetches every A fragment per wave straight from L2: 4 waves x 4 KiB per 192 matrix-pipe cycles =
-// 85 B/clk/CU through a vector-memory path that delivers 64 B/clk/CU at best -- it is L1/TA-bound (measured
-// 40.8 % MFMA busy).  Here the 4 waves of a workgroup share ONE copy of the weight stream in LDS:
-//   * the packed weights (1.47 MB per pass, identical for every pass) flow L2 -> LDS by LDS-DMA
-//     (global_load_lds, 16 B/lane, no VGPRs) into a ring of 8 slots x 16 KiB; a slot is one k-step of all 8
-//     row blocks, hi+lo (or 4 k-steps of the 2-row-block output layer); every wave issues 4 of a slot's 16
-//     1-KiB pieces, 7 slots ahead of consumption;
-//   * per slot: counted s_waitcnt vmcnt(20) (this wave's pieces of slots g and g+1 have landed) -> raw s_barrier
-//     (everybody's have, and everybody is done with slot g-1) -> issue the DMA for slot g+7 into the position of
-//     slot g-1 -> ds_read_b128 fragments (lane-linear image = conflict-free) + 24 MFMAs.  Because slot g+1 is
-//     complete at the barrier of slot g, the 4-deep register ring of fragment reads runs across slot boundaries;
-//   * LDS traffic 16 KiB/slot/wave -> 85 B/clk/CU of 256; L2 -> LDS 16 KiB per slot per CU = 21 B/clk/CU.
-// All small per-style constants (biases, density head) live in LDS as well so that no ordinary global load is
-// in flight inside the layer loops (hipcc drains vmcnt to 0 -- and with it the DMA ring -- before it lets an
-// ordinary load's result be used).
+// Structure of one pass (32 samples per wave through the 7 layers):
+//
+//  * weights: the 4 waves of a workgroup share ONE copy of the packed weight stream (1.47 MB per pass, identical
+//    for every pass).  It flows L2 -> LDS by LDS-DMA (global_load_lds, 16 B/lane, no VGPRs) into a ring of
+//    8 slots x 16 KiB (= 4 units); every wave issues 4 of a slot's 16 1-KiB pieces, 7 slots ahead of use.
+//    Per slot: counted s_waitcnt vmcnt(20) (this wave's pieces of slots g and g+1 have landed) -> raw s_barrier
+//    (everybody's have, and everybody is done with slot g-1) -> DMA for slot g+7 into the position of slot g-1.
+//    Fragments go LDS -> registers by ds_read_b128 (lane-linear image: conflict-free) through a 4-unit register
+//    ring that runs across slot boundaries.  LDS read traffic 85 B/clk/CU of 256, L2 -> LDS 21 B/clk/CU.
+//    (A first version fetched fragments per wave from L2: 85 B/clk/CU through a 64 B/clk/CU path, 40.8 % MFMA busy.)
+//  * the kernel runs ONE wave per SIMD (the 32 samples x 256 activations as hi+lo f16 and the 32 x 256 f32
+//    accumulators take 256 of the 512 registers), so a wave gets one issue slot every ~4 cycles and anything that
+//    is not interleaved with MFMAs is lost matrix time (measured: MFMA-only 10.4 ms + everything-else 12.1 ms =
+//    22.5 ms when the activation epilogues ran between the layers).  Therefore the layer is evaluated as
+//         upper half of the outputs (row blocks 0-3) for all k, then the lower half (4-7),
+//    and the bias + LeakyReLU + f16 hi/lo re-split of a finished half is executed in the shadow of the MFMAs that
+//    follow it: the lower half of layer l while layer l+1 starts on k-steps 0-7 (which only need the upper half),
+//    the upper half of layer l+1 during its own last k-steps 8-15 of the lower half (k-steps 0-7 of its input are
+//    dead by then, so the new B fragments overwrite them).  No second accumulator set is needed.
+//  * density head, volume rendering, clamp, sky blend: VALU epilogue per pass / per ray tile.
 constexpr int NSLOT = 8;
 constexpr int SLOT_BYTES = 16384;
 constexpr int DMA_AHEAD = 7;
@@ -623,103 +418,284 @@ constexpr int LDS_TOTAL = LDS_FLAGS + 64;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const char glb_char;
 
+__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; r++) z[r] = 0.f;
+    return z;
+}
+
+// f32 -> (hi, lo) f16 pair with hi + lo == x to ~2^-22 relative.  Rounding toward zero is as good as
+// round-to-nearest for a split (lo absorbs the remainder) and converts two values per instruction
+// (v_cvt_pkrtz_f16_f32); x - float(hi) is a single v_fma_mix_f32 reading the f16 half directly.
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8 &hi, half8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const fp16x2 hp = __builtin_amdgcn_cvt_pkrtz(v[e], v[e + 1]);
+        const float r0 = __builtin_fmaf((float)hp[0], -1.0f, v[e]);
+        const float r1 = __builtin_fmaf((float)hp[1], -1.0f, v[e + 1]);
+        const fp16x2 lp = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        hi[e] = (_Float16)hp[0];
+        hi[e + 1] = (_Float16)hp[1];
+        lo[e] = (_Float16)lp[0];
+        lo[e + 1] = (_Float16)lp[1];
+    }
+}
+
 struct Ring {
-    int dbg;
     const char *wbytes;   // packed weights
     int g;                // slots consumed so far (uniform across the workgroup)
     int next_in_pass;     // slot-in-pass index of slot g + DMA_AHEAD
-    int wave, lane;
+    int wave;             // wave index as a scalar (readfirstlane)
+    int lane;
+    int voff;             // per-lane byte offset of this wave's first piece inside a slot: wave*4096 + lane*16
 };
 
 __device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_global, int slot_in_pass) {
     const int pos = slot_global & (NSLOT - 1);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int piece = r.wave * 4 + i;
-        const char *src = r.wbytes + (size_t)slot_in_pass * SLOT_BYTES + piece * 1024 + r.lane * 16;
-        char *dst = lds + LDS_RING + pos * SLOT_BYTES + piece * 1024;  // wave-uniform; hardware adds lane*16
-        __builtin_amdgcn_global_load_lds((glb_char *)src, (lds_char *)dst, 16, 0, 0);
-    }
+    // address = uniform (SGPR) slot base + one per-lane VGPR offset + immediate; LDS destination is wave-uniform
+    const char *sbase = r.wbytes + (size_t)slot_in_pass * SLOT_BYTES;
+    char *dbase = lds + LDS_RING + pos * SLOT_BYTES + r.wave * 4096;
+    // the instruction offset is added to the global AND to the LDS address (LDS = M0 + offset + lane*16)
+    glb_char *src = (glb_char *)(sbase + r.voff);
+    __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 3072, 0);
 }
 
-// make slot r.g (and r.g+1) readable for everybody, free slot r.g-1, refill it
+// make slot r.g (and r.g+1) readable for everybody, free slot r.g-1 and refill it
 __device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_AHEAD - 2) * 4) : "memory");
-    if (!(r.dbg & 2)) __builtin_amdgcn_s_barrier();
-    if (!(r.dbg & 1)) ring_issue(lds, r, r.g + DMA_AHEAD, r.next_in_pass);
+    __builtin_amdgcn_s_barrier();
+    ring_issue(lds, r, r.g + DMA_AHEAD, r.next_in_pass);
     r.next_in_pass = r.next_in_pass + 1 == SLOTS_PER_PASS ? 0 : r.next_in_pass + 1;
     const int pos = r.g & (NSLOT - 1);
     r.g++;
     return pos;
 }
 
-template <int NIB>
 __device__ __forceinline__ void lds_unit(const char *lds, int pos, int u_in_slot, int lane, half8 (&a)[4]) {
-    // unit = two row blocks of one k-step: fragments (ib,hi) (ib,lo) (ib+1,hi) (ib+1,lo), 1 KiB each, contiguous
     const char *q = lds + LDS_RING + pos * SLOT_BYTES + u_in_slot * 4096 + lane * 16;
-    a[0] = *reinterpret_cast<const half8 *>(q);
-    a[1] = *reinterpret_cast<const half8 *>(q + 1024);
-    a[2] = *reinterpret_cast<const half8 *>(q + 2048);
-    a[3] = *reinterpret_cast<const half8 *>(q + 3072);
+    a[0] = *reinterpret_cast<const half8 *>(q);          // (ib, hi)
+    a[1] = *reinterpret_cast<const half8 *>(q + 1024);   // (ib, lo)
+    a[2] = *reinterpret_cast<const half8 *>(q + 2048);   // (ib+1, hi)
+    a[3] = *reinterpret_cast<const half8 *>(q + 3072);   // (ib+1, lo)
 }
 
-// One dense layer from the LDS ring.  Units are numbered across the whole layer; 4 units per slot in both
-// layer shapes (NIB=8: one k-step; NIB=2: four k-steps).
-template <int NIB, int NSTEPS>
-__device__ __forceinline__ void gemm_layer_lds(char *lds, Ring &r, const half8 (&bh)[16], const half8 (&bl)[16],
-                                               f32x16 (&acc)[NIB]) {
-    constexpr int PAIRS = NIB / 2, UNITS = NSTEPS * PAIRS, RD = 4, UPS = 4;  // units per slot
-    static_assert(UNITS % UPS == 0, "layer must be a whole number of slots");
-    half8 ring[RD][4];
-    int pos_cur = ring_acquire(lds, r);   // slot of unit 0; the next slot is complete as well
-    int pos_nxt = (pos_cur + 1) & (NSLOT - 1);
+// Per-lane view of a 256-vector in the C/D register layout: element (IB, Q, e) is feature
+// 32*IB + 16*Q + (e&3) + 8*(e>>2) + 4*h.
+// LDS reads of the small constant tables are issued through inline asm: hipcc's waitcnt pass cannot tell them
+// from reads of the DMA ring (same __shared__ array) and would otherwise put `s_waitcnt vmcnt(0)` in front of each
+// one, draining the whole 7-slot DMA pipeline six times per layer (seen in the ISA; ~25 % of the kernel time).
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(const lds_char *)p;
+}
+
+// 4 x 16 B at p, p+32, p+64, p+96 (bytes): the 16 accumulator-layout values of one 32-row block
+__device__ __forceinline__ f32x16 lds_read_block(const float *p) {
+    f32x4 v0, v1, v2, v3;
+    asm volatile(
+        "ds_read_b128 %0, %4\n\t"
+        "ds_read_b128 %1, %4 offset:32\n\t"
+        "ds_read_b128 %2, %4 offset:64\n\t"
+        "ds_read_b128 %3, %4 offset:96\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+        : "v"(lds_addr(p))
+        : "memory");
+    f32x16 c;
 #pragma unroll
-    for (int u = 0; u < RD - 1; u++) lds_unit<NIB>(lds, pos_cur, u, r.lane, ring[u]);
+    for (int e = 0; e < 4; e++) {
+        c[e] = v0[e]; c[4 + e] = v1[e]; c[8 + e] = v2[e]; c[12 + e] = v3[e];
+    }
+    return c;
+}
+
+// 2 x 16 B at p and p+32 (bytes)
+__device__ __forceinline__ void lds_read_8(const float *p, float (&o)[8]) {
+    f32x4 v0, v1;
+    asm volatile(
+        "ds_read_b128 %0, %2\n\t"
+        "ds_read_b128 %1, %2 offset:32\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(v0), "=&v"(v1)
+        : "v"(lds_addr(p))
+        : "memory");
 #pragma unroll
-    for (int u = 0; u < UNITS; u++) {
-        if (u % UPS == 0 && u != 0) {  // entering a new slot: acquire it (also completes the one after it)
-            pos_cur = ring_acquire(lds, r);
-            pos_nxt = (pos_cur + 1) & (NSLOT - 1);
-        }
-        const int un = u + RD - 1;       // unit to prefetch into registers
-        if (un < UNITS) {
-            const bool same_slot = (un / UPS) == (u / UPS);
-            lds_unit<NIB>(lds, same_slot ? pos_cur : pos_nxt, un % UPS, r.lane, ring[un % RD]);
-        }
-        const int s = u / PAIRS, ib = 2 * (u % PAIRS);
-        half8(&a)[4] = ring[u % RD];
-        if (!(r.dbg & 4)) {
-            acc[ib] = mfma16(a[0], bh[s], acc[ib]);
-            acc[ib + 1] = mfma16(a[2], bh[s], acc[ib + 1]);
-            acc[ib] = mfma16(a[1], bh[s], acc[ib]);
-            acc[ib + 1] = mfma16(a[3], bh[s], acc[ib + 1]);
-            acc[ib] = mfma16(a[0], bl[s], acc[ib]);
-            acc[ib + 1] = mfma16(a[2], bl[s], acc[ib + 1]);
-        } else {
-            asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
-        }
-        __builtin_amdgcn_sched_barrier(0);
+    for (int e = 0; e < 4; e++) {
+        o[e] = v0[e]; o[4 + e] = v1[e];
     }
 }
 
-__global__ __launch_bounds__(256, 1) void mlp_kernel_lds(const MlpParams p) {
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;   // plain v_max_f32: fmaxf() adds a canonicalising v_max in front of every operand
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// bias vector of row block IB in accumulator layout (it seeds the accumulator: first MFMA's C operand)
+template <int IB>
+__device__ __forceinline__ f32x16 bias_block(const float *bias, int h) {
+    return lds_read_block(bias + 32 * IB + 4 * h);
+}
+
+// LeakyReLU(0.2) + hi/lo split of 8 accumulator values (bias already inside) = one B fragment pair of the next
+// layer; SIG additionally accumulates the density head (fc_sigma on fc_4's activations, layers.py:114)
+template <int IB, int Q, bool SIG>
+__device__ __forceinline__ void act_group(const f32x16 (&acc)[8], const float *wsig, int h, half8 &oh, half8 &ol, float &part) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float x = acc[IB][8 * Q + e];
+        v[e] = vmax(x, 0.2f * x);
+    }
+    if constexpr (SIG) {
+        float w[8];
+        lds_read_8(wsig + 32 * IB + 16 * Q + 4 * h, w);
+#pragma unroll
+        for (int e = 0; e < 8; e++) part += w[e] * v[e];
+    }
+    split8(v, oh, ol);
+}
+
+template <int T, bool SIG>
+__device__ __forceinline__ void act_step(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16], half8 (&bl)[16],
+                                         float &part) {
+    act_group<T / 2, T % 2, SIG>(acc, wsig, h, bh[T], bl[T], part);
+}
+
+// One 8-row-block layer (NS k-steps) from the LDS ring.
+//   pend:  activation of the PREVIOUS layer's lower half (row blocks 4-7 -> B fragments 8..15), one group per
+//          unit from unit 0 (HAS_PEND), hidden behind this layer's first MFMAs;
+//   own:   activation of this layer's upper half into B fragments 0 .. NS/2-1 during the last NS/2 k-steps of
+//          the lower half.
+// On return acc[0..3] are consumed (except fragments t >= NS/2 when NS == 8), acc[4..7] hold the lower half.
+// Every index below is a compile-time constant (template recursion over the unit number): register arrays must
+// never be indexed dynamically or they end up in scratch memory.
+constexpr int RING_DEPTH = 3;   // register ring of fragment units: 2 units (384 matrix cycles) ahead of the MFMAs
+
+struct LayerState {
+    half8 ring[RING_DEPTH][4];
+    int pos_cur, pos_nxt;
+};
+
+template <int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
+__device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
+                                            f32x16 (&acc)[8], const float *bias, const float *wsig, int h, float &part) {
+    constexpr int UNITS = NS * 4, RD = RING_DEPTH, UPS = 4;
+    if constexpr (U % UPS == 0 && U != 0) {
+        st.pos_cur = ring_acquire(lds, r);
+        st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    }
+    constexpr int UN = U + RD - 1;
+    if constexpr (UN < UNITS)
+        lds_unit(lds, (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt, UN % UPS, r.lane, st.ring[UN % RD]);
+    constexpr int HALF = U / (2 * NS), REM = U % (2 * NS), S = REM >> 1, IB = 4 * HALF + 2 * (REM & 1);
+    half8(&a)[4] = st.ring[U % RD];
+    if constexpr (S == 0) {
+        acc[IB] = mfma16(a[0], bh[S], bias_block<IB>(bias, h));
+        acc[IB + 1] = mfma16(a[2], bh[S], bias_block<IB + 1>(bias, h));
+    } else {
+        acc[IB] = mfma16(a[0], bh[S], acc[IB]);
+        acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
+    }
+    acc[IB] = mfma16(a[1], bh[S], acc[IB]);
+    acc[IB + 1] = mfma16(a[3], bh[S], acc[IB + 1]);
+    acc[IB] = mfma16(a[0], bl[S], acc[IB]);
+    acc[IB + 1] = mfma16(a[2], bl[S], acc[IB + 1]);
+    // ---- VALU work in the shadow of those MFMAs --------------------------------------------------------------
+    // previous layer's lower half -> fragments 8..15: one group every second unit over units 0..15
+    // (fragment 8+k is first needed at unit 16+2k)
+    if constexpr (HAS_PEND && U < 16 && (U % 2 == 0)) act_step<8 + U / 2, SIG_PEND>(acc, wsig, h, bh, bl, part);
+    // own upper half -> fragments 0..NS/2-1 during the last NS/2 k-steps of the lower half
+    if constexpr (HALF == 1 && S >= NS / 2 && ((U - 3 * NS) % 2 == 0))
+        act_step<(U - 3 * NS) / 2, SIG_OWN>(acc, wsig, h, bh, bl, part);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int... Us>
+__device__ __forceinline__ void layer8_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
+                                             half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8], const float *bias,
+                                             const float *wsig, int h, float &part) {
+    (layer8_unit<NS, HAS_PEND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, acc, bias, wsig, h, part), ...);
+}
+
+template <int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN>
+__device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
+                                       const float *bias, const float *wsig, int h, float &part) {
+    LayerState st;
+    st.pos_cur = ring_acquire(lds, r);
+    st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    lds_unit(lds, st.pos_cur, 0, r.lane, st.ring[0]);
+    lds_unit(lds, st.pos_cur, 1, r.lane, st.ring[1]);
+    layer8_units<NS, HAS_PEND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh, bl, acc, bias,
+                                                  wsig, h, part);
+}
+
+// Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of fc_6 is activated behind
+// its first 8 k-steps.
+template <int U>
+__device__ __forceinline__ void out_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
+                                         const f32x16 (&acc)[8], f32x16 (&col)[2], const float *wsig, int h, float &part) {
+    constexpr int UNITS = 16, RD = RING_DEPTH, UPS = 4;
+    if constexpr (U % UPS == 0 && U != 0) {
+        st.pos_cur = ring_acquire(lds, r);
+        st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    }
+    constexpr int UN = U + RD - 1;
+    if constexpr (UN < UNITS)
+        lds_unit(lds, (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt, UN % UPS, r.lane, st.ring[UN % RD]);
+    half8(&a)[4] = st.ring[U % RD];
+    col[0] = mfma16(a[0], bh[U], col[0]);
+    col[1] = mfma16(a[2], bh[U], col[1]);
+    col[0] = mfma16(a[1], bh[U], col[0]);
+    col[1] = mfma16(a[3], bh[U], col[1]);
+    col[0] = mfma16(a[0], bl[U], col[0]);
+    col[1] = mfma16(a[2], bl[U], col[1]);
+    if constexpr (U < 8) act_step<8 + U, false>(acc, wsig, h, bh, bl, part);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int... Us>
+__device__ __forceinline__ void out_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
+                                          half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8], f32x16 (&col)[2],
+                                          const float *wsig, int h, float &part) {
+    (out_unit<Us>(lds, r, st, bh, bl, acc, col, wsig, h, part), ...);
+}
+
+__device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8],
+                                          f32x16 (&col)[2], const float *wsig, int h, float &part) {
+    LayerState st;
+    st.pos_cur = ring_acquire(lds, r);
+    st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    lds_unit(lds, st.pos_cur, 0, r.lane, st.ring[0]);
+    lds_unit(lds, st.pos_cur, 1, r.lane, st.ring[1]);
+    out_units(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, wsig, h, part);
+}
+
+__global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
     const int q = j & 3;
 
-    // constants -> LDS
     float *cst = reinterpret_cast<float *>(lds + LDS_CONST);
     for (int i = threadIdx.x; i < C_TOTAL; i += 256) cst[i] = p.consts[i];
     __syncthreads();
 
     Ring r;
-    r.dbg = p.dbg;
     r.wbytes = reinterpret_cast<const char *>(p.wpk);
     r.g = 0;
-    r.wave = wave;
+    r.wave = __builtin_amdgcn_readfirstlane(wave);
     r.lane = lane;
-    // prologue: slots 0 .. DMA_AHEAD-1 of the first pass
+    r.voff = r.wave * 4096 + lane * 16;
 #pragma unroll
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
     r.next_in_pass = DMA_AHEAD;
@@ -737,9 +713,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel_lds(const MlpParams p) {
         if (lane == 0) flags[wave] = any_hit ? 1 : 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        const bool grp_hit = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        // readfirstlane makes the decision provably uniform: otherwise every loop-carried ring counter / pointer is
+        // classified divergent, lives in VGPRs (spills!) and the DMA cannot use scalar addressing
+        const bool grp_hit = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // flags may be rewritten by the next group only after everyone read them
+        __builtin_amdgcn_s_barrier();   // the next group rewrites the flags only after everyone has read them
 
         float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float carry = 0.f, tsum = 0.f;
@@ -758,36 +736,31 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel_lds(const MlpParams p) {
                 const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 split8(v, bh[s], bl[s]);
             }
-            // ---- fc_1 ------------------------------------------------------------------------------
-            zero_acc<8>(acc);
-            gemm_layer_lds<8, 8>(lds, r, bh, bl, acc);
-            activate(acc, cst + C_LABEL_BIAS + lab * HID, h, bh, bl);
-            // ---- fc_2 .. fc_6 ----------------------------------------------------------------------
-            float sigma = 0.f;
+            float part = 0.f;
+            const float *wsig = cst + C_WSIGMA;
+            // ---- fc_1: 8 k-steps; its upper half is activated into fragments 0..3 behind its own tail, the rest of
+            //      the upper half (fragments 4..7) right after it, its lower half behind fc_2's head ------------------
+            layer8<8, false, false, false>(lds, r, bh, bl, acc, cst + C_LABEL_BIAS + lab * HID, wsig, h, part);
+            act_step<4, false>(acc, wsig, h, bh, bl, part);
+            act_step<5, false>(acc, wsig, h, bh, bl, part);
+            act_step<6, false>(acc, wsig, h, bh, bl, part);
+            act_step<7, false>(acc, wsig, h, bh, bl, part);
+            // ---- fc_2 .. fc_6.  fc_4 (l == 2) feeds the density head (layers.py:114): its upper half is activated
+            //      inside l == 2, its lower half as the pending work of l == 3 ----------------------------------------
 #pragma unroll 1
             for (int l = 0; l < 5; l++) {
-                zero_acc<8>(acc);
-                gemm_layer_lds<8, 16>(lds, r, bh, bl, acc);
-                activate(acc, cst + C_BETA + l * HID, h, bh, bl);
-                if (l == 2) {  // density head on the fp32 activations of fc_4 (layers.py:114)
-                    float part = 0.f;
-#pragma unroll
-                    for (int ib = 0; ib < 8; ib++) {
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; g4++) {
-                            const float4 w = *reinterpret_cast<const float4 *>(cst + C_WSIGMA + 32 * ib + 8 * g4 + 4 * h);
-                            part += w.x * acc[ib][4 * g4] + w.y * acc[ib][4 * g4 + 1] + w.z * acc[ib][4 * g4 + 2] +
-                                    w.w * acc[ib][4 * g4 + 3];
-                        }
-                    }
-                    sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
-                }
+                const float *bias = cst + C_BETA + l * HID;
+                if (l == 2) layer8<16, true, false, true>(lds, r, bh, bl, acc, bias, wsig, h, part);
+                else if (l == 3) layer8<16, true, true, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
+                else layer8<16, true, false, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
             }
-            // ---- fc_out_c ----------------------------------------------------------------------------
+            // ---- fc_out_c ------------------------------------------------------------------------------------------
             f32x16 col[2];
-            load_rowvec<2>(cst + C_BC, h, col);
-            gemm_layer_lds<2, 16>(lds, r, bh, bl, col);
-            // ---- volume rendering (mc_utils.py:154-161) ---------------------------------------------------
+            col[0] = bias_block<0>(cst + C_BC, h);
+            col[1] = bias_block<1>(cst + C_BC, h);
+            layer_out(lds, r, bh, bl, acc, col, wsig, h, part);
+            const float sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
+            // ---- volume rendering (mc_utils.py:154-161) over the 4 samples of each ray in this pass ---------------
             const float fe = fmaxf(sigma, 0.f) * dist;
             float incl = fe;
             float up = __shfl_up(incl, 1, 4);
@@ -806,13 +779,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel_lds(const MlpParams p) {
                 for (int rr = 0; rr < 16; rr++) {
                     const float rgb = fminf(fmaxf(col[ib][rr], -1.f), 1.f) + 1.f;  // scenedreamer.py:408
                     float v = wgt * rgb;
-                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 1);   // sum over the 4 samples of the ray held by this quad
                     v += __shfl_xor(v, 2);
                     if ((rr >> 2) == q) outq[ib][rr & 3] += v;
                 }
         }
 
-        // ---- blend the sky, store ---------------------------------------------------------------------
+        // ---- blend the sky, store ---------------------------------------------------------------------------------
         tsum += __shfl_xor(tsum, 1);
         tsum += __shfl_xor(tsum, 2);
         const bool sky_only = flag & 1, nosky = flag & 2;
@@ -821,7 +794,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel_lds(const MlpParams p) {
         if (ray_ok) {
 #pragma unroll
             for (int ib = 0; ib < 2; ib++) {
-                const int f0 = 32 * ib + 8 * q + 4 * h;
+                const int f0 = 32 * ib + 8 * q + 4 * h;   // this lane owns features f0 .. f0+3 of its ray
                 const float4 sc = *reinterpret_cast<const float4 *>(p.sky_c + (size_t)ray * OUTC + f0);
                 const float4 sa = *reinterpret_cast<const float4 *>(cst + C_SKY_AVG + f0);
                 const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sav[4] = {sa.x, sa.y, sa.z, sa.w};
@@ -996,25 +969,10 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     p.R = n_rays; p.ns = num_samples;
     p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
     p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
-    {
-        const char *e = getenv("SDN_MLP_DBG");
-        p.dbg = e ? atoi(e) : 0;
-    }
     int wg = n_workgroups > 0 ? n_workgroups : 256;
-    const int need = sdn::div_up(p.n_tiles, 4);
-    if (wg > need) wg = need;
-    static const int variant = [] {
-        const char *e = getenv("SDN_MLP_VARIANT");   // "l2": v0 (weights straight from L2), default: LDS ring
-        return (e && e[0] == 'l' && e[1] == '2') ? 0 : 1;
-    }();
-    if (variant == 0) {
-        hipLaunchKernelGGL(mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
-    } else {
-        const int groups = sdn::div_up(p.n_tiles, 4);
-        int wgl = n_workgroups > 0 ? n_workgroups : 256;
-        if (wgl > groups) wgl = groups;
-        hipLaunchKernelGGL(mlp_kernel_lds, dim3(wgl), dim3(256), 0, (hipStream_t)stream, p);
-    }
+    const int groups = sdn::div_up(p.n_tiles, 4);
+    if (wg > groups) wg = groups;
+    hipLaunchKernelGGL(mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_mlp");
 }
 
