@@ -166,7 +166,7 @@ def main():
     for k in range(min(args.steps, 5)):
         R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, timers=stages)
     stage_ms = {k: float(np.mean(v)) for k, v in stages.items()}
-    roof = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
+    roof, roof_grid = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
 
     if rank == 0:
         fps = world * args.steps / elapsed
@@ -180,7 +180,7 @@ def main():
                                    f"1 frame per rank per step", "path": mode, "padded_rays": (hw[0] + 30) * (hw[1] + 30),
                        "samples_per_frame": (hw[0] + 30) * (hw[1] + 30) * args.samples, "parallelism": f"frames x{world}"},
             "stage_ms": stage_ms, "setup_s": setup_s,
-            "roofline": roof,
+            "roofline": roof, "roofline_grid_sampler": roof_grid,
         }
         if world == 1 and not args.no_cpu_baseline:
             small = synth.make_scene(256, 3407)

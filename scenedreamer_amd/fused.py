@@ -114,6 +114,27 @@ def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns):
     return net_out
 
 
+def time_mlp_kernel(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, reps=5):
+    """(samples per launch, avg ms) of mlp_kernel alone (features already encoded)."""
+    from .renderer import _time_ms
+    st = R._fused_style or prepare_style(R)
+    n = vid.numel() // R.M
+    vid, d2, rd = vid.reshape(n, R.M).contiguous(), d2.reshape(2, n, R.M).contiguous(), rd.reshape(n, 3).contiguous()
+    buf = encode(R, vid, d2, rd, cam_ori, ns)
+    st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
+    net_out = torch.empty((n, 64), dtype=torch.float32, device=R.dev)
+    sky_c = sky_c.contiguous()
+
+    def launch():
+        with torch.cuda.device(R.dev):
+            capi.check(_lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
+                                            buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
+                                            sky_c.data_ptr(), net_out.data_ptr(), n, ns, 0, _stream(R.dev)))
+    ms = _time_ms(launch, reps)
+    hit = float((vid[:, 0] != 0).float().mean())
+    return n * ns, ms, hit
+
+
 def time_encode_kernel(R, vid, d2, rd, cam_ori, ns, reps=5):
     """(samples per launch, avg ms, algorithmic bytes per sample, kernel name) for the roofline record."""
     from .renderer import _time_ms

@@ -1,0 +1,161 @@
+"""Host-side logic that needs no GPU: camera trajectory, tile arithmetic, synthetic data determinism,
+the C ABI's export table and argument validation."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden
+
+
+def test_camera_poses_match_reference_controller(scene256):
+    """camera.eval_camera_poses == EvalCameraController(pattern=0) recorded from the reference (camctl.py:20-50)."""
+    from scenedreamer_amd import camera
+    g = golden("camera_pattern0.npz")
+    poses = camera.eval_camera_poses(scene256, maxstep=int(g["maxstep"]))
+    assert len(poses) == 8
+    for i, (o, d, u, f) in enumerate(poses):
+        np.testing.assert_array_equal(o.numpy(), g["ori"][i])
+        np.testing.assert_array_equal(d.numpy(), g["dir"][i])
+        np.testing.assert_array_equal(u.numpy(), g["up"][i])
+        assert f == g["f"][i]
+
+
+@pytest.mark.needs_reference
+def test_camera_poses_match_live_reference(scene256):
+    from oracle import ref_harness as RH
+    RH.install("oracle")
+    import imaginaire.model_utils.gancraft.camctl as camctl
+    from scenedreamer_amd import camera
+    ctl = camctl.EvalCameraController(scene256, maxstep=12, pattern=0, cam_ang=72, smooth_decay_multiplier=150 / 12)
+    mine = camera.eval_camera_poses(scene256, maxstep=12)
+    for a, b in zip(ctl, mine):
+        for x, y in zip(a[:3], b[:3]):
+            np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+        assert a[3] == b[3]
+
+
+def test_tile_grid_and_intrinsics():
+    from scenedreamer_amd import camera
+    f, c, cam_res = camera.frame_intrinsics(0.5 / np.tan(np.deg2rad(36)), (540, 960), 30)
+    assert cam_res == [570, 990] and c == [284.5, 494.5]
+    assert abs(f - 0.5 / np.tan(np.deg2rad(36)) * 959) < 1e-9
+    tiles, nh, nw = camera.tile_grid(cam_res, 30)
+    assert (nh, nw, len(tiles)) == (5, 8, 40)
+    assert sum((a[1] - a[0]) * (a[3] - a[2]) for a in tiles) == 828000
+    tiles3, nh3, nw3 = camera.tile_grid([1110, 1950], 30)
+    assert (nh3, nw3) == (9, 15) and sum((a[1] - a[0]) * (a[3] - a[2]) for a in tiles3) == 3199500
+
+
+def test_level_offsets_of_the_scenedreamer_grid():
+    from scenedreamer_amd.gridencoder import level_offsets
+    pls = np.exp2(np.log2(2048 / 16) / 15)
+    offs = level_offsets(5, 16, pls, 16, 19, False)
+    assert offs.tolist() == [524288 * i for i in range(17)]
+    small = level_offsets(2, 4, 2.0, 4, 19, False)
+    assert small.tolist() == [0, 32, 32 + 88, 32 + 88 + 296, 32 + 88 + 296 + 1096]   # (res+1)^2 rounded up to 8
+
+
+def test_synthetic_data_is_deterministic_and_well_formed(scene256, lut):
+    from scenedreamer_amd import synth
+    u = synth.hash_u01(5, "x", 4)
+    np.testing.assert_array_equal(u, synth.hash_u01(5, "x", 6)[:4])
+    assert not np.array_equal(u, synth.hash_u01(6, "x", 4))
+    np.testing.assert_array_equal(synth.uniform(1, "a", (7,), -1, 1), synth.uniform(1, "a", (7,), -1, 1))
+    s2 = synth.make_scene(256, 3407)
+    assert torch.equal(s2.voxel_t, scene256.voxel_t)
+    v = scene256.voxel_t
+    assert v.dtype == torch.int32 and v.dim() == 3 and v.shape[1:] == (256, 256)
+    ids = set(np.unique(v.numpy()).tolist())
+    assert ids <= {0, 1, 8, 9, 26, 28, 30, 34, 58}
+    assert all(lut[i] != 0 or i == 0 for i in ids)                  # every id has a reduced label
+    assert lut[34] == 2 and lut[58] == 2                             # tree blocks
+    assert scene256.current_semantic_map.shape == (1, 11, 256, 256)
+    assert scene256.current_semantic_map[0, 10].sum() > 0            # >= 1 tree pixel (layers.py:28 needs 11 channels)
+    assert float(scene256.trans_mat[0, 3]) == float(scene256.heightmap.min())
+    w = synth.make_weights(0, with_embeddings=False)
+    assert w["render_net.fc_1.weight"].shape == (256, 128) and w["render_net.fc_m_a.weight"].shape == (256, 12)
+    assert w["denoiser.conv2a.weight"].shape == (256, 256, 3, 3) and "denoiser.conv2b.bias" not in w
+
+
+def test_label_lut():
+    from scenedreamer_amd.renderer import load_label_lut
+    d = load_label_lut()
+    assert len(d["lut"]) == 680 and d["num_reduced"] == 12 and d["ignore_id"] == 0 and d["dirt_id"] == 3
+    assert d["lut"][0] == 1                                           # air -> sky
+    assert [d["lut"][i] for i in (28, 9, 8, 1, 30, 26)] == [10, 3, 5, 9, 6, 7]
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "sdnative.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sdn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from scenedreamer_amd import capi
+    lib = capi.lib()
+    declared = _header_symbols()
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/sdnative.h but not exported"
+    assert set(capi.declared_symbols()) <= set(declared)
+    assert lib.sdn_abi_version() == 1
+
+
+def test_argument_validation_without_a_gpu():
+    """Unsupported shapes are rejected before any launch, with the reference's error text."""
+    from scenedreamer_amd import capi
+    lib = capi.lib()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    rc = lib.sdn_grid_encode_fwd(p, p, 0, p, p, 8, 3, 3, 1, 0.0, 4, 0, p, 0, 0, None)
+    assert rc == -2 and b"C must be 1, 2, 4, or 8" in lib.sdn_last_error()
+    rc = lib.sdn_grid_encode_fwd(p, p, 0, p, p, 8, 6, 2, 1, 0.0, 4, 0, p, 0, 0, None)
+    assert rc == -2 and b"D must be" in lib.sdn_last_error()
+    rc = lib.sdn_rvip(None, p, p, p, p, p, 1.0, p, p, 2, p, p, p, None)
+    assert rc == -1
+    assert lib.sdn_posenc_fwd(None, None, 0, 5, 3, 1, None) == 0           # empty input is a no-op
+    offs = (ctypes.c_int32 * 17)(*[100 * i for i in range(17)])
+    rc = lib.sdn_field_collapse_table(p, ctypes.addressof(offs), 16, 0.4667, 16, p, p, None)
+    assert rc == -2 and b"power-of-two" in lib.sdn_last_error()
+
+
+def test_level_scales_agree_with_oracle(oracle):
+    from scenedreamer_amd import capi
+    S = np.float32(np.log2(np.exp2(np.log2(2048 / 16) / 15)))
+    sc = np.empty(16, np.float32)
+    res = np.empty(16, np.uint32)
+    assert capi.lib().sdn_grid_level_scales(16, float(S), 16, sc.ctypes.data, res.ctypes.data) == 0
+    for l in range(16):
+        s, r = oracle.level_params(l, S, 16)
+        assert sc[l] == np.float32(s) and res[l] == r
+
+
+def test_ops_fail_loudly_on_cpu_tensors():
+    from scenedreamer_amd import ops
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.positional_encoding(torch.zeros(4, 3), 2, -1, True)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.ray_voxel_intersection_perspective(torch.zeros(2, 2, 2, dtype=torch.int32), torch.zeros(3), torch.ones(3),
+                                               torch.ones(3), 1.0, [0, 0], [2, 2], 1)
+    with pytest.raises(NotImplementedError):
+        ops.sp_trilinear_worldcoord()
+
+
+def test_shims_are_importable():
+    import scenedreamer_amd
+    scenedreamer_amd.install_shims()
+    import _gridencoder
+    import bias_act_cuda  # noqa: F401
+    import gridencoder
+    import upfirdn2d_cuda  # noqa: F401
+    import voxlib
+    assert callable(voxlib.ray_voxel_intersection_perspective) and callable(voxlib.positional_encoding)
+    assert callable(_gridencoder.grid_encode_forward) and callable(_gridencoder.grid_encode_backward)
+    enc = gridencoder.GridEncoder(input_dim=5, desired_resolution=2048, level_dim=8, log2_hashmap_size=8)
+    assert enc.output_dim == 128 and tuple(enc.embeddings.shape) == (16 * 256, 8)
+    assert "embeddings" in enc.state_dict() and "offsets" in enc.state_dict()
