@@ -141,6 +141,25 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
                   int32_t n_workgroups, sdn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Render CNN: the four 3x3 256->256 convolutions of RenderCNN (conv2a/2b/3a/3b,
+ * imaginaire/generators/gancraft_base.py:175-225) on MFMA with the field MLP's 3-term f16 split.
+ * Activations travel between the convolutions as two f16 planes (hi, lo) [Hb*Wb][256] with a zero border
+ * (extent from sdn_conv_plane_dims; the caller zero-fills the planes ONCE, kernels never write the border or
+ * pixels outside the H x W frame); fp32 tensors are rows [H*W][256] (channels last).
+ *   out = LeakyReLU_0.2( (resid + conv(in) + bias) * (mod_w + 1) + mod_b )      each term optional
+ */
+void sdn_conv_plane_dims(int H, int W, int *Hb, int *Wb);
+size_t sdn_conv_packed_weight_bytes(void);
+/* w_oihw dev f32 [256,256,3,3] -> packed dev */
+int sdn_conv_pack_weights(const float *w_oihw, void *packed, sdn_stream_t stream);
+/* x dev f32 [H*W,256] -> hi/lo planes */
+int sdn_conv_planes_from_f32(const float *x, void *out_hi, void *out_lo, int H, int W, sdn_stream_t stream);
+int sdn_conv3x3(const void *in_hi, const void *in_lo, const void *packed, const float *bias, const float *resid,
+                const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32, int H, int W,
+                int n_workgroups, sdn_stream_t stream);
+
 /* test hook: C[32,32] = A[32,16] * B[16,32] through the MFMA operand layouts field.hip relies on */
 int sdn_debug_mfma_probe(const float *A, const float *B, float *C, sdn_stream_t stream);
 

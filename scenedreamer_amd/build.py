@@ -25,6 +25,7 @@ SOURCES = {
     "posenc.hip": [],
     "gridenc.hip": [],
     "field.hip": [],
+    "cnn.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,334 @@
+// 3x3 convolution 256 -> 256 of the render CNN on MFMA for gfx950 (RenderCNN.conv2a/2b/3a/3b,
+// imaginaire/generators/gancraft_base.py:175-225), with the same 3-term f16 split / f32 accumulate arithmetic
+// as the field MLP (field.hip): the image must stay within 1e-3 of the fp32 reference, which plain f16 does not.
+//
+// Formulation (transposed implicit GEMM): D^T[cout][pixel] = sum_{tap, cin} W[cout][cin][tap] * X[cin][pixel + tap].
+//   * MFMA columns = 32 pixels (an 8 x 4 patch) per wave, 4 waves (a 16 x 8 patch) per workgroup;
+//     all 256 output channels of the patch live in 128 accumulator registers;
+//   * K = 9 taps x 256 channels = 144 k-steps of 16.  Per k-step a workgroup needs 16 KiB of weight fragments
+//     (shared by its 4 waves, hi + lo) and every wave 2 KiB of its own activation fragments (hi + lo):
+//     BOTH arrive by LDS-DMA.  For the activations the per-lane global address of global_load_lds is the
+//     gather (pixel + tap, 8 consecutive channels = 16 B) and the lane-linear LDS image IS the MFMA B fragment;
+//     activations are stored as two f16 planes [padded pixel][256] with a zero border, so taps need no branches;
+//   * 6-slot LDS ring (24 KiB per slot), 5 k-steps ahead, counted vmcnt + raw s_barrier per k-step exactly as
+//     in field.hip; because every vector-memory operation in the main loop is a DMA with the same look-ahead, no
+//     wait ever drains the pipeline (ordinary loads of B would: vmcnt completes in order);
+//   * epilogue variants: bias + LeakyReLU -> f16 planes (conv2a/3a);  residual + style FiLM + LeakyReLU ->
+//     fp32 rows and/or f16 planes (conv2b/3b, gancraft_base.py:197-200, :213-217).
+// Roofline: MFMA (f16 dense peak); 3456 MFMAs per wave per 32 pixels.
+#include <hip/hip_fp16.h>
+
+#include <cstdlib>
+
+#include "sdn_common.h"
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) const char glb_char;
+
+constexpr int CH = 256;
+constexpr int KSTEPS = 9 * 16;            // 144
+constexpr int A_BYTES = 16384;            // weight fragments of one k-step (8 row blocks, hi + lo)
+constexpr int B_BYTES = 2048;             // one wave's activation fragments of one k-step (hi + lo)
+constexpr int SLOT_BYTES = A_BYTES + 4 * B_BYTES;   // 24 KiB
+constexpr int NSLOT = 6;
+constexpr int AHEAD = 5;
+constexpr int DMA_PER_SLOT = 6;           // per wave: 4 weight pieces + 2 activation pieces
+constexpr int TILE_W = 8, TILE_H = 4;
+
+struct ConvParams {
+    const _Float16 *xh, *xl;   // input planes [Hb*Wb][256], zero border and zero outside the frame
+    const char *wpk;           // packed weights, KSTEPS * 16 KiB
+    const float *bias;         // [256] or nullptr
+    const float *resid;        // fp32 [H*W][256] or nullptr
+    const float *mod_w;        // [256] FiLM scale (applied as w + 1) or nullptr
+    const float *mod_b;        // [256]
+    _Float16 *oh, *ol;         // output planes or nullptr
+    float *of32;               // fp32 [H*W][256] or nullptr
+    int H, W, Hb, Wb;          // frame and padded-buffer extent (buffer pixel (y,x) -> (y+1, x+1))
+    int gx, gy, n_groups;      // workgroup patches (16 x 8 pixels)
+};
+
+__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// DMA of k-step `kt` of a pass into ring position `pos`
+__device__ __forceinline__ void issue_slot(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
+    // weights: this wave's 4 of the 16 1-KiB pieces
+    const char *wsrc = p.wpk + (size_t)kt * A_BYTES + wave * 4096 + lane * 16;
+    char *wdst = lds + pos * SLOT_BYTES + wave * 4096;
+    __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 3072, 0);
+    // activations: tap = kt / 16 (ky = tap / 3, kx = tap % 3), channels 16*(kt % 16) + 8h .. +7 of pixel + tap
+    const int tap = kt >> 4, s = kt & 15;
+    const long toff = ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * (CH * 2) + s * 32;
+    char *bdst = lds + pos * SLOT_BYTES + A_BYTES + wave * B_BYTES;
+    __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + toff), (lds_char *)bdst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xl + boff + toff), (lds_char *)(bdst + 1024), 16, 0, 0);
+}
+
+__device__ __forceinline__ void lds_unit(const char *slot, int u, int lane, half8 (&a)[4]) {
+    const char *q = slot + u * 4096 + lane * 16;
+    a[0] = *reinterpret_cast<const half8 *>(q);
+    a[1] = *reinterpret_cast<const half8 *>(q + 1024);
+    a[2] = *reinterpret_cast<const half8 *>(q + 2048);
+    a[3] = *reinterpret_cast<const half8 *>(q + 3072);
+}
+
+__device__ __forceinline__ long lane_pixel_offset(const ConvParams &p, int grp, int wave, int lane, int &py, int &px) {
+    const int gyi = grp / p.gx, gxi = grp - gyi * p.gx;
+    const int j = lane & 31, h = lane >> 5;
+    py = gyi * (2 * TILE_H) + (wave >> 1) * TILE_H + (j >> 3);
+    px = gxi * (2 * TILE_W) + (wave & 1) * TILE_W + (j & 7);
+    return ((long)(py + 1) * p.Wb + (px + 1)) * (CH * 2) + h * 16;
+}
+
+__global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[NSLOT * SLOT_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5;
+
+    int grp = blockIdx.x;
+    if (grp >= p.n_groups) return;
+    int py, px;
+    long boff = lane_pixel_offset(p, grp, wave, lane, py, px);
+    int grp_n = grp + gridDim.x;
+    int pyn, pxn;
+    long boff_n = grp_n < p.n_groups ? lane_pixel_offset(p, grp_n, wave, lane, pyn, pxn) : boff;
+
+    int pos_issue = 0, pos_use = 0;
+#pragma unroll
+    for (int q = 0; q < AHEAD; q++) {
+        issue_slot(lds, p, pos_issue, q, wave, lane, boff);
+        pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
+    }
+
+    // Fragment registers: a[u] = weight unit u of the current k-step (4 x 16 B each), bh/bl = this wave's
+    // activation fragments.  Units 0,1 and the activations of k-step kt+1 are fetched from LDS during units 2,3 of
+    // k-step kt (slot kt+1 is complete at the barrier of kt), so no k-step starts with an exposed LDS round trip.
+    half8 a[4][4];
+    half8 bh, bl;
+    bool primed = false;
+
+    while (true) {
+        f32x16 acc[8];
+#pragma unroll 1
+        for (int kt = 0; kt < KSTEPS; kt++) {
+            // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free -----
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
+            __builtin_amdgcn_s_barrier();
+            {
+                const int qn = kt + AHEAD;   // k-step to fetch, possibly of the next patch
+                if (qn < KSTEPS) issue_slot(lds, p, pos_issue, qn, wave, lane, boff);
+                else issue_slot(lds, p, pos_issue, qn - KSTEPS, wave, lane, boff_n);
+                pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
+            }
+            const char *slot = lds + pos_use * SLOT_BYTES;
+            pos_use = pos_use + 1 == NSLOT ? 0 : pos_use + 1;
+            const char *slot_n = lds + pos_use * SLOT_BYTES;
+            if (!primed) {   // very first k-step of the kernel only
+                lds_unit(slot, 0, lane, a[0]);
+                lds_unit(slot, 1, lane, a[1]);
+                bh = *reinterpret_cast<const half8 *>(slot + A_BYTES + wave * B_BYTES + lane * 16);
+                bl = *reinterpret_cast<const half8 *>(slot + A_BYTES + wave * B_BYTES + 1024 + lane * 16);
+                primed = true;
+            }
+            half8 bh_n, bl_n;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ib = 2 * u;
+                if (kt == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[r] = 0.f;
+                    acc[ib] = mfma16(a[u][0], bh, z);
+                    acc[ib + 1] = mfma16(a[u][2], bh, z);
+                } else {
+                    acc[ib] = mfma16(a[u][0], bh, acc[ib]);
+                    acc[ib + 1] = mfma16(a[u][2], bh, acc[ib + 1]);
+                }
+                acc[ib] = mfma16(a[u][1], bh, acc[ib]);
+                acc[ib + 1] = mfma16(a[u][3], bh, acc[ib + 1]);
+                acc[ib] = mfma16(a[u][0], bl, acc[ib]);
+                acc[ib + 1] = mfma16(a[u][2], bl, acc[ib + 1]);
+                // prefetch two units ahead: units 2,3 of this slot, then units 0,1 (+ activations) of the next slot
+                if (u == 0) lds_unit(slot, 2, lane, a[2]);
+                if (u == 1) lds_unit(slot, 3, lane, a[3]);
+                if (u == 2) {
+                    lds_unit(slot_n, 0, lane, a[0]);
+                    bh_n = *reinterpret_cast<const half8 *>(slot_n + A_BYTES + wave * B_BYTES + lane * 16);
+                    bl_n = *reinterpret_cast<const half8 *>(slot_n + A_BYTES + wave * B_BYTES + 1024 + lane * 16);
+                }
+                if (u == 3) lds_unit(slot_n, 1, lane, a[1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bh = bh_n;
+            bl = bl_n;
+        }
+
+        // ---- epilogue of this patch -----------------------------------------------------------------------------
+        const bool in_frame = py < p.H && px < p.W;
+        if (in_frame) {
+            const long orow = (long)py * p.W + px;                          // fp32 rows are unpadded
+            const long prow = ((long)(py + 1) * p.Wb + (px + 1)) * CH;      // planes are padded
+#pragma unroll
+            for (int ib = 0; ib < 8; ib++) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const int c0 = 32 * ib + 8 * g4 + 4 * h;                // 4 consecutive channels
+                    float v[4] = {acc[ib][4 * g4], acc[ib][4 * g4 + 1], acc[ib][4 * g4 + 2], acc[ib][4 * g4 + 3]};
+                    if (p.bias) {
+                        const float4 b = *reinterpret_cast<const float4 *>(p.bias + c0);
+                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                    }
+                    if (p.resid) {   // y = y + conv(...)   (gancraft_base.py:213, :216)
+                        const float4 r = *reinterpret_cast<const float4 *>(p.resid + orow * CH + c0);
+                        v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
+                    }
+                    if (p.mod_w) {   // modulate: x * (w + 1) + b   (:197-200)
+                        const float4 mw = *reinterpret_cast<const float4 *>(p.mod_w + c0);
+                        const float4 mb = *reinterpret_cast<const float4 *>(p.mod_b + c0);
+                        v[0] = v[0] * (mw.x + 1.f) + mb.x; v[1] = v[1] * (mw.y + 1.f) + mb.y;
+                        v[2] = v[2] * (mw.z + 1.f) + mb.z; v[3] = v[3] * (mw.w + 1.f) + mb.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = vmax(v[e], 0.2f * v[e]);   // LeakyReLU(0.2)
+                    if (p.of32) *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                    if (p.oh) {
+                        const fp16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+                        const fp16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
+                        const fp16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
+                        half4 hv, lv;
+                        hv[0] = (_Float16)h0[0]; hv[1] = (_Float16)h0[1]; hv[2] = (_Float16)h1[0]; hv[3] = (_Float16)h1[1];
+                        lv[0] = (_Float16)l0[0]; lv[1] = (_Float16)l0[1]; lv[2] = (_Float16)l1[0]; lv[3] = (_Float16)l1[1];
+                        *reinterpret_cast<half4 *>(p.oh + prow + c0) = hv;
+                        *reinterpret_cast<half4 *>(p.ol + prow + c0) = lv;
+                    }
+                }
+            }
+        }
+        // ---- next patch ---------------------------------------------------------------------------------------------
+        grp = grp_n;
+        if (grp >= p.n_groups) break;
+        boff = boff_n;
+        py = pyn;
+        px = pxn;
+        grp_n = grp + gridDim.x;
+        boff_n = grp_n < p.n_groups ? lane_pixel_offset(p, grp_n, wave, lane, pyn, pxn) : boff;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// ---- weight packing: W [256][256][3][3] (PyTorch OIHW) -> [k-step t = tap*16 + s][unit][frag][64 lanes][8] ------------
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict__ W, half8 *__restrict__ out) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // (t, ib, lane)
+    if (g >= (size_t)KSTEPS * 8 * 64) return;
+    const int lane = (int)(g % 64);
+    const int ib = (int)((g / 64) % 8);
+    const int t = (int)(g / (64 * 8));
+    const int tap = t >> 4, s = t & 15;
+    const int co = 32 * ib + (lane & 31), h = lane >> 5;
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int ci = 16 * s + 8 * h + e;
+        const float v = W[((size_t)co * CH + ci) * 9 + tap];
+        const _Float16 vh = (_Float16)v;
+        hi[e] = vh;
+        lo[e] = (_Float16)(v - (float)vh);
+    }
+    // unit = ib / 2; fragments (ib,hi) (ib,lo) (ib+1,hi) (ib+1,lo)
+    const size_t base = ((size_t)t * 16 + (size_t)(ib / 2) * 4 + (ib & 1) * 2) * 64 + lane;
+    out[base] = hi;
+    out[base + 64] = lo;
+}
+
+// ---- fp32 rows [H*W][256] -> padded f16 hi / lo planes ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void planes_kernel(const float *__restrict__ x, _Float16 *__restrict__ oh,
+                                                     _Float16 *__restrict__ ol, int H, int W, int Wb) {
+    const long n = (long)H * W * (CH / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long pix = i / (CH / 4);
+        const int c0 = (int)(i % (CH / 4)) * 4;
+        const int y = (int)(pix / W), xx = (int)(pix % W);
+        const float4 v = *reinterpret_cast<const float4 *>(x + pix * CH + c0);
+        const fp16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+        const fp16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
+        const fp16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
+        half4 hv, lv;
+        hv[0] = (_Float16)h0[0]; hv[1] = (_Float16)h0[1]; hv[2] = (_Float16)h1[0]; hv[3] = (_Float16)h1[1];
+        lv[0] = (_Float16)l0[0]; lv[1] = (_Float16)l0[1]; lv[2] = (_Float16)l1[0]; lv[3] = (_Float16)l1[1];
+        const long o = ((long)(y + 1) * Wb + (xx + 1)) * CH + c0;
+        *reinterpret_cast<half4 *>(oh + o) = hv;
+        *reinterpret_cast<half4 *>(ol + o) = lv;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// padded plane extent for an H x W frame: multiples of the 16 x 8 workgroup patch + 1-pixel zero border
+void sdn_conv_plane_dims(int H, int W, int *Hb, int *Wb) {
+    *Hb = sdn::div_up(H, 2 * TILE_H) * 2 * TILE_H + 2;
+    *Wb = sdn::div_up(W, 2 * TILE_W) * 2 * TILE_W + 2;
+}
+
+size_t sdn_conv_packed_weight_bytes(void) { return (size_t)KSTEPS * A_BYTES; }
+
+int sdn_conv_pack_weights(const float *w_oihw, void *packed, sdn_stream_t stream) {
+    SDN_REQUIRE(w_oihw && packed, "sdn_conv_pack_weights: null pointer");
+    const size_t n = (size_t)KSTEPS * 8 * 64;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)sdn::div_up<size_t>(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, (half8 *)packed);
+    return sdn::check_launch("sdn_conv_pack_weights");
+}
+
+int sdn_conv_planes_from_f32(const float *x, void *out_hi, void *out_lo, int H, int W, sdn_stream_t stream) {
+    SDN_REQUIRE(x && out_hi && out_lo && H > 0 && W > 0, "sdn_conv_planes_from_f32: bad argument");
+    int Hb, Wb;
+    sdn_conv_plane_dims(H, W, &Hb, &Wb);
+    hipLaunchKernelGGL(planes_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, (_Float16 *)out_hi, (_Float16 *)out_lo,
+                       H, W, Wb);
+    return sdn::check_launch("sdn_conv_planes_from_f32");
+}
+
+int sdn_conv3x3(const void *in_hi, const void *in_lo, const void *packed, const float *bias, const float *resid,
+                const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32, int H, int W,
+                int n_workgroups, sdn_stream_t stream) {
+    SDN_REQUIRE(in_hi && in_lo && packed && H > 0 && W > 0, "sdn_conv3x3: bad argument");
+    SDN_REQUIRE((out_hi && out_lo) || out_f32, "sdn_conv3x3: no output requested");
+    SDN_REQUIRE((mod_w == nullptr) == (mod_b == nullptr), "sdn_conv3x3: mod_w and mod_b go together");
+    ConvParams p;
+    p.xh = (const _Float16 *)in_hi; p.xl = (const _Float16 *)in_lo; p.wpk = (const char *)packed;
+    p.bias = bias; p.resid = resid; p.mod_w = mod_w; p.mod_b = mod_b;
+    p.oh = (_Float16 *)out_hi; p.ol = (_Float16 *)out_lo; p.of32 = out_f32;
+    p.H = H; p.W = W;
+    sdn_conv_plane_dims(H, W, &p.Hb, &p.Wb);
+    p.gx = sdn::div_up(W, 2 * TILE_W);
+    p.gy = sdn::div_up(H, 2 * TILE_H);
+    p.n_groups = p.gx * p.gy;
+    int wg = n_workgroups > 0 ? n_workgroups : 256;
+    if (wg > p.n_groups) wg = p.n_groups;
+    hipLaunchKernelGGL(conv3x3_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_conv3x3");
+}
+
+}  // extern "C"

@@ -253,7 +253,7 @@ class Renderer:
 
     # ------------------------------------------------------------------ frame
     def render_frame(self, pose, resolution_hw=(540, 960), num_samples=24, mode="unfused", cnn=True,
-                     ray_chunk=1 << 16, timers=None):
+                     ray_chunk=1 << 16, timers=None, cnn_mode=None):
         """One frame of the trajectory.  Returns image [1,3,H,W] (or net_out [1,Hp,Wp,64] if cnn=False)."""
         ev = _Stamps(timers)
         with torch.no_grad():
@@ -286,7 +286,15 @@ class Renderer:
             if not cnn:
                 ev.done()
                 return net_out
-            img = self.render_cnn(net_out)
+            if cnn_mode is None:
+                cnn_mode = "mfma" if mode == "fused" else "torch"
+            if cnn_mode == "mfma":
+                if getattr(self, "_mfma_cnn", None) is None:
+                    from .cnn import MfmaCNN
+                    self._mfma_cnn = MfmaCNN(self)
+                img = self._mfma_cnn(net_out)
+            else:
+                img = self.render_cnn(net_out)
             p = self.pad // 2
             if self.pad:
                 img = img[:, :, p:-p, p:-p]

@@ -90,3 +90,15 @@ def test_full_frame_equals_reference_tiling(renderer, weights_full, scene256, lu
     assert tuple(img.shape) == (1, 3, 140, 150)
     err = np.abs(img.cpu().numpy() - ref.numpy())
     assert err.max() < TOL, f"image max abs err {err.max():.3e}"
+
+
+def test_mfma_cnn_matches_torch_cnn(renderer):
+    """RenderCNN on the MFMA 3x3 kernels vs the same network through PyTorch/MIOpen fp32, frame with ragged edges."""
+    from scenedreamer_amd.cnn import MfmaCNN
+    torch.manual_seed(0)
+    for hw in ((37, 53), (64, 96)):
+        x = (torch.rand(1, hw[0], hw[1], 64, device="cuda") * 2 - 1)
+        ref = renderer.render_cnn(x)
+        got = MfmaCNN(renderer)(x)
+        err = (got - ref).abs().max().item()
+        assert got.shape == ref.shape and err < 2e-4, f"max abs err {err:.3e}"
