@@ -24,7 +24,7 @@ SOURCES = {
     "rvip.hip": ["-ffp-contract=off"],  # bit-exact vs the oracle: no FMA contraction
     "posenc.hip": [],
     "gridenc.hip": [],
-    "field.hip": [],
+    "field.hip": (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
     "cnn.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

@@ -435,17 +435,18 @@ __device__ __forceinline__ f32x16 zero16() {
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split8(const float (&v)[8], half8 &hi, half8 &lo) {
+    unsigned int hw[4], lw[4];
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
         const fp16x2 hp = __builtin_amdgcn_cvt_pkrtz(v[e], v[e + 1]);
-        const float r0 = __builtin_fmaf((float)hp[0], -1.0f, v[e]);
-        const float r1 = __builtin_fmaf((float)hp[1], -1.0f, v[e + 1]);
-        const fp16x2 lp = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-        hi[e] = (_Float16)hp[0];
-        hi[e + 1] = (_Float16)hp[1];
-        lo[e] = (_Float16)lp[0];
-        lo[e + 1] = (_Float16)lp[1];
+        const fp16x2 lp = __builtin_amdgcn_cvt_pkrtz(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
+        hw[e / 2] = __builtin_bit_cast(unsigned int, hp);
+        lw[e / 2] = __builtin_bit_cast(unsigned int, lp);
     }
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h4 = {hw[0], hw[1], hw[2], hw[3]}, l4 = {lw[0], lw[1], lw[2], lw[3]};
+    hi = __builtin_bit_cast(half8, h4);
+    lo = __builtin_bit_cast(half8, l4);
 }
 
 struct Ring {
@@ -471,10 +472,11 @@ __device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_gl
 }
 
 // make slot r.g (and r.g+1) readable for everybody, free slot r.g-1 and refill it
+template <int DBG>
 __device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_AHEAD - 2) * 4) : "memory");
-    __builtin_amdgcn_s_barrier();
-    ring_issue(lds, r, r.g + DMA_AHEAD, r.next_in_pass);
+    if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+    if constexpr (!(DBG & 1)) ring_issue(lds, r, r.g + DMA_AHEAD, r.next_in_pass);
     r.next_in_pass = r.next_in_pass + 1 == SLOTS_PER_PASS ? 0 : r.next_in_pass + 1;
     const int pos = r.g & (NSLOT - 1);
     r.g++;
@@ -546,29 +548,94 @@ __device__ __forceinline__ f32x16 bias_block(const float *bias, int h) {
     return lds_read_block(bias + 32 * IB + 4 * h);
 }
 
-// LeakyReLU(0.2) + hi/lo split of 8 accumulator values (bias already inside) = one B fragment pair of the next
-// layer; SIG additionally accumulates the density head (fc_sigma on fc_4's activations, layers.py:114)
-template <int IB, int Q, bool SIG>
-__device__ __forceinline__ void act_group(const f32x16 (&acc)[8], const float *wsig, int h, half8 &oh, half8 &ol, float &part) {
-    float v[8];
+// Activation of 4 accumulator values (half a B fragment), cut into 6 stages of <= 6 mutually INDEPENDENT VALU
+// instructions.  With one wave per SIMD instructions issue in order: a VALU instruction behind an MFMA that waits
+// for the matrix pipe waits too, and back-to-back dependent VALU instructions cost ~10 cycles each.  Putting one
+// stage after each of a unit's 6 MFMAs (and fencing with sched_barrier) gives every MFMA gap ~5 independent
+// instructions: the activation then costs no matrix time.  (Measured before this change: the same instructions,
+// emitted as per-value dependent chains after the unit's last MFMA, took 9.2 ms of a 19.2 ms kernel.)
+//   fragment T = 2*IB + Q of the next layer, HS = which 4 of its 8 elements:
+//   value e is accumulator register 8*Q + 4*HS + e of row block IB = feature 32*IB + 16*Q + 8*HS + e + 4*h
+struct ActRegs {
+    float x[4], y[4];
+    fp16x2 hp[2], lp[2];
+    f32x4 w;
+};
+
+// plain v_max_f32 (fmaxf / fmed3 get a canonicalising v_max in front of every operand)
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+// write two packed f16 pairs into dwords 2*HS, 2*HS+1 of a fragment (whole-dword moves: 16-bit element inserts
+// into a half8 are lowered through scratch memory by hipcc)
+template <int HS>
+__device__ __forceinline__ void put_pairs(half8 &frag, fp16x2 p0, fp16x2 p1) {
+    u32x4v t = __builtin_bit_cast(u32x4v, frag);
+    t[2 * HS] = __builtin_bit_cast(unsigned int, p0);
+    t[2 * HS + 1] = __builtin_bit_cast(unsigned int, p1);
+    frag = __builtin_bit_cast(half8, t);
+}
+
+template <int T, int HS, bool SIG, int STAGE>
+__device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16], half8 (&bl)[16],
+                                          float &part, ActRegs &g) {
+    constexpr int IB = T / 2, Q = T % 2;
+    if constexpr (STAGE == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const float x = acc[IB][8 * Q + e];
-        v[e] = vmax(x, 0.2f * x);
-    }
-    if constexpr (SIG) {
-        float w[8];
-        lds_read_8(wsig + 32 * IB + 16 * Q + 4 * h, w);
+        for (int e = 0; e < 4; e++) g.x[e] = acc[IB][8 * Q + 4 * HS + e];                 // 4 x v_accvgpr_read
+        if constexpr (SIG) {   // density-head weights of these 4 features (one 16-B LDS read, asm: see lds_read_block)
+            asm volatile("ds_read_b128 %0, %1" : "=v"(g.w) : "v"(lds_addr(wsig + 32 * IB + 16 * Q + 8 * HS + 4 * h)) : "memory");
+        }
+    } else if constexpr (STAGE == 1) {
 #pragma unroll
-        for (int e = 0; e < 8; e++) part += w[e] * v[e];
+        for (int e = 0; e < 4; e++) g.y[e] = 0.2f * g.x[e];
+    } else if constexpr (STAGE == 2) {
+        // LeakyReLU(0.2) = max(x, 0.2 x)
+#pragma unroll
+        for (int e = 0; e < 4; e++) g.x[e] = vmax_raw(g.x[e], g.y[e]);
+    } else if constexpr (STAGE == 3) {
+        g.hp[0] = __builtin_amdgcn_cvt_pkrtz(g.x[0], g.x[1]);
+        g.hp[1] = __builtin_amdgcn_cvt_pkrtz(g.x[2], g.x[3]);
+        if constexpr (SIG) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g.w)::"memory");
+            part += g.w[0] * g.x[0] + g.w[1] * g.x[1] + g.w[2] * g.x[2] + g.w[3] * g.x[3];
+        }
+    } else if constexpr (STAGE == 4) {
+        g.y[0] = g.x[0] - (float)g.hp[0][0];
+        g.y[1] = g.x[1] - (float)g.hp[0][1];
+        g.y[2] = g.x[2] - (float)g.hp[1][0];
+        g.y[3] = g.x[3] - (float)g.hp[1][1];
+    } else {
+        g.lp[0] = __builtin_amdgcn_cvt_pkrtz(g.y[0], g.y[1]);
+        g.lp[1] = __builtin_amdgcn_cvt_pkrtz(g.y[2], g.y[3]);
+        put_pairs<HS>(bh[T], g.hp[0], g.hp[1]);
+        put_pairs<HS>(bl[T], g.lp[0], g.lp[1]);
     }
-    split8(v, oh, ol);
+}
+
+// whole half-fragment at once (used where nothing can hide it: the tail of fc_1)
+template <int T, int HS, bool SIG>
+__device__ __forceinline__ void act_half(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16], half8 (&bl)[16],
+                                         float &part) {
+    ActRegs g;
+    act_stage<T, HS, SIG, 0>(acc, wsig, h, bh, bl, part, g);
+    act_stage<T, HS, SIG, 1>(acc, wsig, h, bh, bl, part, g);
+    act_stage<T, HS, SIG, 2>(acc, wsig, h, bh, bl, part, g);
+    act_stage<T, HS, SIG, 3>(acc, wsig, h, bh, bl, part, g);
+    act_stage<T, HS, SIG, 4>(acc, wsig, h, bh, bl, part, g);
+    act_stage<T, HS, SIG, 5>(acc, wsig, h, bh, bl, part, g);
 }
 
 template <int T, bool SIG>
 __device__ __forceinline__ void act_step(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16], half8 (&bl)[16],
                                          float &part) {
-    act_group<T / 2, T % 2, SIG>(acc, wsig, h, bh[T], bl[T], part);
+    act_half<T, 0, SIG>(acc, wsig, h, bh, bl, part);
+    act_half<T, 1, SIG>(acc, wsig, h, bh, bl, part);
 }
 
 // One 8-row-block layer (NS k-steps) from the LDS ring.
@@ -586,100 +653,139 @@ struct LayerState {
     int pos_cur, pos_nxt;
 };
 
-template <int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
+// one LDS read of the register ring's next unit (fragment F of unit UN)
+__device__ __forceinline__ void lds_frag(const char *lds, int pos, int u_in_slot, int lane, int f, half8 &dst) {
+    dst = *reinterpret_cast<const half8 *>(lds + LDS_RING + pos * SLOT_BYTES + u_in_slot * 4096 + f * 1024 + lane * 16);
+}
+
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
 __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
                                             f32x16 (&acc)[8], const float *bias, const float *wsig, int h, float &part) {
     constexpr int UNITS = NS * 4, RD = RING_DEPTH, UPS = 4;
     if constexpr (U % UPS == 0 && U != 0) {
-        st.pos_cur = ring_acquire(lds, r);
+        st.pos_cur = ring_acquire<DBG>(lds, r);
         st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
     }
     constexpr int UN = U + RD - 1;
-    if constexpr (UN < UNITS)
-        lds_unit(lds, (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt, UN % UPS, r.lane, st.ring[UN % RD]);
+    constexpr bool PF = UN < UNITS && !(DBG & 8);
+    const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
     constexpr int HALF = U / (2 * NS), REM = U % (2 * NS), S = REM >> 1, IB = 4 * HALF + 2 * (REM & 1);
+    // activation work hidden in this unit: the previous layer's lower half (fragments 8..15, half a fragment per
+    // unit over units 0..15: fragment 8+k is first needed at unit 16+2k), or this layer's upper half
+    // (fragments 0..NS/2-1) during the last NS/2 k-steps of the lower half
+    constexpr bool PEND = HAS_PEND && U < 16 && !(DBG & 4);
+    constexpr bool OWN = HALF == 1 && S >= NS / 2 && !(DBG & 4);
+    constexpr int M = U - 3 * NS;
+    constexpr int T = PEND ? 8 + U / 2 : (OWN ? M / 2 : 0);
+    constexpr int HS = PEND ? U % 2 : (OWN ? M % 2 : 0);
+    constexpr bool SIG = PEND ? SIG_PEND : SIG_OWN;
+    constexpr bool ACT = PEND || OWN;
+    ActRegs g;
     half8(&a)[4] = st.ring[U % RD];
-    if constexpr (S == 0) {
-        acc[IB] = mfma16(a[0], bh[S], bias_block<IB>(bias, h));
-        acc[IB + 1] = mfma16(a[2], bh[S], bias_block<IB + 1>(bias, h));
-    } else {
-        acc[IB] = mfma16(a[0], bh[S], acc[IB]);
-        acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
-    }
-    acc[IB] = mfma16(a[1], bh[S], acc[IB]);
-    acc[IB + 1] = mfma16(a[3], bh[S], acc[IB + 1]);
-    acc[IB] = mfma16(a[0], bl[S], acc[IB]);
-    acc[IB + 1] = mfma16(a[2], bl[S], acc[IB + 1]);
-    // ---- VALU work in the shadow of those MFMAs --------------------------------------------------------------
-    // previous layer's lower half -> fragments 8..15: one group every second unit over units 0..15
-    // (fragment 8+k is first needed at unit 16+2k)
-    if constexpr (HAS_PEND && U < 16 && (U % 2 == 0)) act_step<8 + U / 2, SIG_PEND>(acc, wsig, h, bh, bl, part);
-    // own upper half -> fragments 0..NS/2-1 during the last NS/2 k-steps of the lower half
-    if constexpr (HALF == 1 && S >= NS / 2 && ((U - 3 * NS) % 2 == 0))
-        act_step<(U - 3 * NS) / 2, SIG_OWN>(acc, wsig, h, bh, bl, part);
+    half8(&nx)[4] = st.ring[UN % RD];
+#define SDN_STAGE(K) \
+    if constexpr (ACT) act_stage<T, HS, SIG, K>(acc, wsig, h, bh, bl, part, g); \
+    if constexpr (PF && K < 4) lds_frag(lds, pf_pos, UN % UPS, r.lane, (K) & 3, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG & 16) {
+        asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(bh[S]), "v"(bl[S]));
+        if constexpr (S == 0) { acc[IB] = bias_block<IB>(bias, h); acc[IB + 1] = bias_block<IB + 1>(bias, h); }
+        SDN_STAGE(0) SDN_STAGE(1) SDN_STAGE(2) SDN_STAGE(3) SDN_STAGE(4) SDN_STAGE(5)
+    } else {
+        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], bias_block<IB>(bias, h));
+        else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
+        SDN_STAGE(0)
+        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], bias_block<IB + 1>(bias, h));
+        else acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
+        SDN_STAGE(1)
+        acc[IB] = mfma16(a[1], bh[S], acc[IB]);
+        SDN_STAGE(2)
+        acc[IB + 1] = mfma16(a[3], bh[S], acc[IB + 1]);
+        SDN_STAGE(3)
+        acc[IB] = mfma16(a[0], bl[S], acc[IB]);
+        SDN_STAGE(4)
+        acc[IB + 1] = mfma16(a[2], bl[S], acc[IB + 1]);
+        SDN_STAGE(5)
+    }
+#undef SDN_STAGE
 }
 
-template <int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int... Us>
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int... Us>
 __device__ __forceinline__ void layer8_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
                                              half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8], const float *bias,
                                              const float *wsig, int h, float &part) {
-    (layer8_unit<NS, HAS_PEND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, acc, bias, wsig, h, part), ...);
+    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, acc, bias, wsig, h, part), ...);
 }
 
-template <int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN>
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN>
 __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
                                        const float *bias, const float *wsig, int h, float &part) {
     LayerState st;
-    st.pos_cur = ring_acquire(lds, r);
+    st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
     lds_unit(lds, st.pos_cur, 0, r.lane, st.ring[0]);
     lds_unit(lds, st.pos_cur, 1, r.lane, st.ring[1]);
-    layer8_units<NS, HAS_PEND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh, bl, acc, bias,
+    layer8_units<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh, bl, acc, bias,
                                                   wsig, h, part);
 }
 
 // Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of fc_6 is activated behind
 // its first 8 k-steps.
-template <int U>
+template <int DBG, int U>
 __device__ __forceinline__ void out_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
                                          const f32x16 (&acc)[8], f32x16 (&col)[2], const float *wsig, int h, float &part) {
     constexpr int UNITS = 16, RD = RING_DEPTH, UPS = 4;
     if constexpr (U % UPS == 0 && U != 0) {
-        st.pos_cur = ring_acquire(lds, r);
+        st.pos_cur = ring_acquire<DBG>(lds, r);
         st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
     }
     constexpr int UN = U + RD - 1;
-    if constexpr (UN < UNITS)
-        lds_unit(lds, (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt, UN % UPS, r.lane, st.ring[UN % RD]);
+    constexpr bool PF = UN < UNITS && !(DBG & 8);
+    const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
+    // fc_6's lower half -> fragments 8..15, one whole fragment per unit over units 0..7 (fragment 8+k is needed at unit 8+k)
+    constexpr bool ACT = U < 8 && !(DBG & 4);
+    constexpr int T = ACT ? 8 + U : 8;
+    ActRegs g0, g1;
     half8(&a)[4] = st.ring[U % RD];
-    col[0] = mfma16(a[0], bh[U], col[0]);
-    col[1] = mfma16(a[2], bh[U], col[1]);
-    col[0] = mfma16(a[1], bh[U], col[0]);
-    col[1] = mfma16(a[3], bh[U], col[1]);
-    col[0] = mfma16(a[0], bl[U], col[0]);
-    col[1] = mfma16(a[2], bl[U], col[1]);
-    if constexpr (U < 8) act_step<8 + U, false>(acc, wsig, h, bh, bl, part);
+    half8(&nx)[4] = st.ring[UN % RD];
+#define SDN_STAGE(K) \
+    if constexpr (ACT) { act_stage<T, 0, false, K>(acc, wsig, h, bh, bl, part, g0); act_stage<T, 1, false, K>(acc, wsig, h, bh, bl, part, g1); } \
+    if constexpr (PF && K < 4) lds_frag(lds, pf_pos, UN % UPS, r.lane, (K) & 3, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
+    col[0] = mfma16(a[0], bh[U], col[0]);
+    SDN_STAGE(0)
+    col[1] = mfma16(a[2], bh[U], col[1]);
+    SDN_STAGE(1)
+    col[0] = mfma16(a[1], bh[U], col[0]);
+    SDN_STAGE(2)
+    col[1] = mfma16(a[3], bh[U], col[1]);
+    SDN_STAGE(3)
+    col[0] = mfma16(a[0], bl[U], col[0]);
+    SDN_STAGE(4)
+    col[1] = mfma16(a[2], bl[U], col[1]);
+    SDN_STAGE(5)
+#undef SDN_STAGE
 }
 
-template <int... Us>
+template <int DBG, int... Us>
 __device__ __forceinline__ void out_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
                                           half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8], f32x16 (&col)[2],
                                           const float *wsig, int h, float &part) {
-    (out_unit<Us>(lds, r, st, bh, bl, acc, col, wsig, h, part), ...);
+    (out_unit<DBG, Us>(lds, r, st, bh, bl, acc, col, wsig, h, part), ...);
 }
 
+template <int DBG>
 __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8],
                                           f32x16 (&col)[2], const float *wsig, int h, float &part) {
     LayerState st;
-    st.pos_cur = ring_acquire(lds, r);
+    st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
     lds_unit(lds, st.pos_cur, 0, r.lane, st.ring[0]);
     lds_unit(lds, st.pos_cur, 1, r.lane, st.ring[1]);
-    out_units(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, wsig, h, part);
+    out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, wsig, h, part);
 }
 
+template <int DBG>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -740,7 +846,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             const float *wsig = cst + C_WSIGMA;
             // ---- fc_1: 8 k-steps; its upper half is activated into fragments 0..3 behind its own tail, the rest of
             //      the upper half (fragments 4..7) right after it, its lower half behind fc_2's head ------------------
-            layer8<8, false, false, false>(lds, r, bh, bl, acc, cst + C_LABEL_BIAS + lab * HID, wsig, h, part);
+            layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, cst + C_LABEL_BIAS + lab * HID, wsig, h, part);
             act_step<4, false>(acc, wsig, h, bh, bl, part);
             act_step<5, false>(acc, wsig, h, bh, bl, part);
             act_step<6, false>(acc, wsig, h, bh, bl, part);
@@ -750,15 +856,15 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
 #pragma unroll 1
             for (int l = 0; l < 5; l++) {
                 const float *bias = cst + C_BETA + l * HID;
-                if (l == 2) layer8<16, true, false, true>(lds, r, bh, bl, acc, bias, wsig, h, part);
-                else if (l == 3) layer8<16, true, true, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
-                else layer8<16, true, false, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
+                if (l == 2) layer8<DBG, 16, true, false, true>(lds, r, bh, bl, acc, bias, wsig, h, part);
+                else if (l == 3) layer8<DBG, 16, true, true, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
+                else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
             }
             // ---- fc_out_c ------------------------------------------------------------------------------------------
             f32x16 col[2];
             col[0] = bias_block<0>(cst + C_BC, h);
             col[1] = bias_block<1>(cst + C_BC, h);
-            layer_out(lds, r, bh, bl, acc, col, wsig, h, part);
+            layer_out<DBG>(lds, r, bh, bl, acc, col, wsig, h, part);
             const float sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
             // ---- volume rendering (mc_utils.py:154-161) over the 4 samples of each ray in this pass ---------------
             const float fe = fmaxf(sigma, 0.f) * dist;
@@ -972,7 +1078,20 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     int wg = n_workgroups > 0 ? n_workgroups : 256;
     const int groups = sdn::div_up(p.n_tiles, 4);
     if (wg > groups) wg = groups;
-    hipLaunchKernelGGL(mlp_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    static const int dbg = [] {
+        const char *e = getenv("SDN_MLP_DBG");   // timing experiments only; results are wrong unless 0
+        return e ? atoi(e) : 0;
+    }();
+    switch (dbg) {
+#ifdef SDN_MLP_ABLATION
+        case 1: hipLaunchKernelGGL(mlp_kernel<1>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring DMA
+        case 4: hipLaunchKernelGGL(mlp_kernel<4>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no activation VALU
+        case 8: hipLaunchKernelGGL(mlp_kernel<8>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no fragment ds_read
+        case 16: hipLaunchKernelGGL(mlp_kernel<16>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // no MFMA
+        case 28: hipLaunchKernelGGL(mlp_kernel<28>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+#endif
+        default: hipLaunchKernelGGL(mlp_kernel<0>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+    }
     return sdn::check_launch("sdn_field_mlp");
 }
 
