@@ -55,6 +55,7 @@ constexpr int RAYS_PER_TILE = 8;
 constexpr int SAMP_PER_STEP = 4;
 constexpr int MAXM = 8;
 constexpr int MAX_LIN = 80;     // up to 78 samples per ray
+constexpr float ACT_SCALE = 0.4f; // LeakyReLU_0.2(x) = 0.4 * (1.5 x + |x|)
 
 // ---- packed weight layout (in units of half8 = one lane's fragment) ---------------------------------
 // layer 0: fc_1   K=128 -> 8 k-steps, 8 row blocks
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int k = layer == 0 ? kmap_first(s, h, e) : kmap_hidden(s, h, e);
-        const float v = W[(size_t)row * K + k];
+        // layers 1..6 consume a' = 1.5 x + |x| = LeakyReLU_0.2(x) / 0.4 (one v_fma instead of mul + max in the
+        // MLP kernel's activation), so their weights carry the factor 0.4
+        const float v = W[(size_t)row * K + k] * (layer == 0 ? 1.0f : ACT_SCALE);
         const _Float16 vh = (_Float16)v;
         hi[e] = vh;
         lo[e] = (_Float16)(v - (float)vh);
@@ -587,32 +590,33 @@ __device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const float *w
     constexpr int IB = T / 2, Q = T % 2;
     if constexpr (STAGE == 0) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) g.x[e] = acc[IB][8 * Q + 4 * HS + e];                 // 4 x v_accvgpr_read
+        for (int e = 0; e < 4; e++) g.y[e] = acc[IB][8 * Q + 4 * HS + e];                 // 4 x v_accvgpr_read
         if constexpr (SIG) {   // density-head weights of these 4 features (one 16-B LDS read, asm: see lds_read_block)
             asm volatile("ds_read_b128 %0, %1" : "=v"(g.w) : "v"(lds_addr(wsig + 32 * IB + 16 * Q + 8 * HS + 4 * h)) : "memory");
         }
     } else if constexpr (STAGE == 1) {
+        // a' = 1.5 x + |x| = LeakyReLU_0.2(x) / 0.4 : ONE v_fma (|x| is a free source modifier); the 0.4 lives in
+        // the next layer's packed weights and in the density-head weights
 #pragma unroll
-        for (int e = 0; e < 4; e++) g.y[e] = 0.2f * g.x[e];
+        for (int e = 0; e < 4; e++) g.x[e] = __builtin_fmaf(g.y[e], 1.5f, __builtin_fabsf(g.y[e]));
     } else if constexpr (STAGE == 2) {
-        // LeakyReLU(0.2) = max(x, 0.2 x)
-#pragma unroll
-        for (int e = 0; e < 4; e++) g.x[e] = vmax_raw(g.x[e], g.y[e]);
-    } else if constexpr (STAGE == 3) {
         g.hp[0] = __builtin_amdgcn_cvt_pkrtz(g.x[0], g.x[1]);
         g.hp[1] = __builtin_amdgcn_cvt_pkrtz(g.x[2], g.x[3]);
+    } else if constexpr (STAGE == 3) {
+        // remainder x - float(hi) in one v_fma_mix_f32 per value (reads the f16 half directly)
+        const unsigned int p0 = __builtin_bit_cast(unsigned int, g.hp[0]), p1 = __builtin_bit_cast(unsigned int, g.hp[1]);
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[0]) : "v"(p0), "v"(g.x[0]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[1]) : "v"(p0), "v"(g.x[1]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[2]) : "v"(p1), "v"(g.x[2]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[3]) : "v"(p1), "v"(g.x[3]));
+    } else if constexpr (STAGE == 4) {
+        g.lp[0] = __builtin_amdgcn_cvt_pkrtz(g.y[0], g.y[1]);
+        g.lp[1] = __builtin_amdgcn_cvt_pkrtz(g.y[2], g.y[3]);
         if constexpr (SIG) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g.w)::"memory");
             part += g.w[0] * g.x[0] + g.w[1] * g.x[1] + g.w[2] * g.x[2] + g.w[3] * g.x[3];
         }
-    } else if constexpr (STAGE == 4) {
-        g.y[0] = g.x[0] - (float)g.hp[0][0];
-        g.y[1] = g.x[1] - (float)g.hp[0][1];
-        g.y[2] = g.x[2] - (float)g.hp[1][0];
-        g.y[3] = g.x[3] - (float)g.hp[1][1];
     } else {
-        g.lp[0] = __builtin_amdgcn_cvt_pkrtz(g.y[0], g.y[1]);
-        g.lp[1] = __builtin_amdgcn_cvt_pkrtz(g.y[2], g.y[3]);
         put_pairs<HS>(bh[T], g.hp[0], g.hp[1]);
         put_pairs<HS>(bl[T], g.lp[0], g.lp[1]);
     }

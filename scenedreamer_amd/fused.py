@@ -58,7 +58,8 @@ def prepare_style(R):
     off = [lib.sdn_field_const_offset(i) for i in range(6)]
     consts[off[0]:off[0] + 12 * 256] = R.label_bias.reshape(-1)
     consts[off[1]:off[1] + 5 * 256] = torch.stack([R.mod[i][1] for i in (2, 3, 4, 5, 6)]).reshape(-1)
-    consts[off[2]:off[2] + 256] = w["render_net.fc_sigma.weight"].reshape(-1)
+    # the MLP kernel's activations are LeakyReLU(x) / 0.4 (see field.hip act_stage): the density head absorbs the 0.4
+    consts[off[2]:off[2] + 256] = w["render_net.fc_sigma.weight"].reshape(-1) * 0.4
     consts[off[3]:off[3] + 64] = w["render_net.fc_out_c.bias"]
     consts[off[4]] = w["render_net.fc_sigma.bias"].reshape(-1)[0]
     R._fused_style = dict(packed=packed, consts=consts, sky_off=off[5], keep=wh)
