@@ -160,6 +160,16 @@ int sdn_conv3x3(const void *in_hi, const void *in_lo, const void *packed, const 
                 const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32, int H, int W,
                 int n_workgroups, sdn_stream_t stream);
 
+/* Sky MLP for every ray + per-feature sum over rays: SKYMLP.forward(positional_encoding(raydirs, 5, incl_orig), z)
+ * (imaginaire/generators/gancraft_base.py:150-169; the frame mean of scenedreamer.py:592-598 = sky_sum / n_rays).
+ * consts (sdn_sky_consts_floats floats): [fc1.bias + fc_z_a(z) : 256][fc2..fc5 bias : 4x256][fc_out_c.bias : 64];
+ * w1 dev [256,33]; wh4_host host array of 4 dev pointers [256,256]; wc dev [64,256]; sky_sum dev [64] pre-zeroed. */
+size_t sdn_sky_packed_weight_bytes(void);
+size_t sdn_sky_consts_floats(void);
+int sdn_sky_pack_weights(const float *w1, const float *const *wh4_host, const float *wc, void *packed, sdn_stream_t stream);
+int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_sum, int32_t n_rays,
+                int32_t n_workgroups, sdn_stream_t stream);
+
 /* test hook: C[32,32] = A[32,16] * B[16,32] through the MFMA operand layouts field.hip relies on */
 int sdn_debug_mfma_probe(const float *A, const float *B, float *C, sdn_stream_t stream);
 

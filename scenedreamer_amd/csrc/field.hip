@@ -453,6 +453,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], half8 &hi, half8 &lo
 }
 
 struct Ring {
+    int slots_per_pass;   // 92 for the field MLP, 72 for the sky MLP
     const char *wbytes;   // packed weights
     int g;                // slots consumed so far (uniform across the workgroup)
     int next_in_pass;     // slot-in-pass index of slot g + DMA_AHEAD
@@ -480,7 +481,7 @@ __device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_AHEAD - 2) * 4) : "memory");
     if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
     if constexpr (!(DBG & 1)) ring_issue(lds, r, r.g + DMA_AHEAD, r.next_in_pass);
-    r.next_in_pass = r.next_in_pass + 1 == SLOTS_PER_PASS ? 0 : r.next_in_pass + 1;
+    r.next_in_pass = r.next_in_pass + 1 == r.slots_per_pass ? 0 : r.next_in_pass + 1;
     const int pos = r.g & (NSLOT - 1);
     r.g++;
     return pos;
@@ -801,6 +802,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     __syncthreads();
 
     Ring r;
+    r.slots_per_pass = SLOTS_PER_PASS;
     r.wbytes = reinterpret_cast<const char *>(p.wpk);
     r.g = 0;
     r.wave = __builtin_amdgcn_readfirstlane(wave);
@@ -920,6 +922,173 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         }
     }
     // the ring runs DMA_AHEAD slots ahead of the last pass: let it land before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+// =====================================================================================================
+// Sky MLP: SKYMLP.forward on PE(raydir) (imaginaire/generators/gancraft_base.py:150-169; positional encoding
+// .../voxlib/positional_encoding_kernel.cu:40-75) for every ray of the frame + the frame mean (scenedreamer.py:592-598)
+// =====================================================================================================
+// Same machinery as mlp_kernel (transposed register-resident chain, 3-term f16 split, LDS weight ring):
+// 32 rays per wave, layers 33(->64 padded) -> 256 -> 256 x4 -> 64.  The style term fc_z_a(z) is folded into fc1's
+// bias on the host.  The per-feature sum over rays (for sky_avg) is reduced per wave and added with one atomic
+// per feature per wave.
+constexpr int SKY_IN = 33, SKY_K0 = 64;                       // encoded ray direction, padded to 4 k-steps
+constexpr int SKY_SLOTS = 4 + 4 * 16 + 4;                     // 72
+constexpr size_t SKY_L0_FRAGS = 16 * 4 * 64;                  // 16 units
+constexpr size_t SKY_PACKED_FRAGS = SKY_L0_FRAGS + 4 * LH_FRAGS + LO_FRAGS;
+constexpr int SC_BIAS1 = 0;                                   // [256] fc1.bias + fc_z_a(z)
+constexpr int SC_BIASH = 256;                                 // [4][256] fc2..fc5 bias
+constexpr int SC_BC = SC_BIASH + 4 * 256;                     // [64]
+constexpr int SC_TOTAL = SC_BC + 64;
+
+struct SkyParams {
+    const float *raydirs;   // [R,3]
+    const half8 *wpk;
+    const float *consts;    // SC_TOTAL floats
+    float *sky_c;           // [R,64]
+    float *sky_sum;         // [64], pre-zeroed by the caller; sum over rays of sky_c
+    int32_t R, n_tiles;
+};
+
+struct SkyPackParams {
+    const float *w1;        // [256,33]
+    const float *wh[4];     // [256,256]
+    const float *wc;        // [64,256]
+    half8 *out;
+};
+
+__global__ __launch_bounds__(256) void sky_pack_kernel(const SkyPackParams p) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n0 = 16 * 2 * 64, nh = 64 * 2 * 64, no = 16 * 2 * 64;
+    if (g >= n0 + 4 * nh + no) return;
+    int layer, nib, ns, K;
+    const float *W;
+    size_t base, r = g;
+    if (r < n0) {
+        layer = 0; nib = 8; ns = 4; K = SKY_IN; W = p.w1; base = 0;
+    } else if (r < n0 + 4 * nh) {
+        r -= n0; layer = 1 + (int)(r / nh); r %= nh; nib = 8; ns = 16; K = HID; W = p.wh[layer - 1];
+        base = SKY_L0_FRAGS + (size_t)(layer - 1) * LH_FRAGS;
+    } else {
+        r -= n0 + 4 * nh; layer = 5; nib = 2; ns = 16; K = HID; W = p.wc; base = SKY_L0_FRAGS + 4 * LH_FRAGS;
+    }
+    const int lane = (int)(r % 64); r /= 64;
+    const int sel = (int)(r % 2);
+    const int u = (int)(r / 2);
+    int s, ib0;
+    unit_coords(nib, ns, u, s, ib0);
+    const int row = 32 * (ib0 + sel) + (lane & 31), h = lane >> 5;
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = layer == 0 ? kmap_first(s, h, e) : kmap_hidden(s, h, e);
+        float v = 0.f;
+        if (k < K) v = W[(size_t)row * K + k] * (layer == 0 ? 1.0f : ACT_SCALE);
+        const _Float16 vh = (_Float16)v;
+        hi[e] = vh;
+        lo[e] = (_Float16)(v - (float)vh);
+    }
+    p.out[base + ((size_t)u * 4 + 2 * sel + 0) * 64 + lane] = hi;
+    p.out[base + ((size_t)u * 4 + 2 * sel + 1) * 64 + lane] = lo;
+}
+
+// element k of the positional encoding of direction d: [sin_0(3) cos_0(3) ... sin_4(3) cos_4(3) d(3)], zero padding
+__device__ __forceinline__ float sky_pe(int k, float d0, float d1, float d2) {
+    if (k >= SKY_IN) return 0.f;
+    const int c = k % 3;
+    const float x = c == 0 ? d0 : (c == 1 ? d1 : d2);
+    if (k >= 30) return x;
+    const int i = k / 6;
+    const float rad = x * 3.141592654f * exp2f((float)i);    // positional_encoding_kernel.cu:63
+    return ((k % 6) < 3) ? sinf(rad) : cosf(rad);
+}
+
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    float *cst = reinterpret_cast<float *>(lds + LDS_CONST);
+    for (int i = threadIdx.x; i < SC_TOTAL; i += 256) cst[i] = p.consts[i];
+    __syncthreads();
+
+    Ring r;
+    r.slots_per_pass = SKY_SLOTS;
+    r.wbytes = reinterpret_cast<const char *>(p.wpk);
+    r.g = 0;
+    r.wave = __builtin_amdgcn_readfirstlane(wave);
+    r.lane = lane;
+    r.voff = r.wave * 4096 + lane * 16;
+#pragma unroll
+    for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
+    r.next_in_pass = DMA_AHEAD;
+
+    float fsum[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // lane (q = j&3, h) owns features 32*ib + 8*q + 4*h + e
+    const int q = j & 3;
+    const int n_groups = (p.n_tiles + 3) >> 2;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int tile = grp * 4 + wave;
+        const int ray = tile * 32 + j;
+        const bool ray_ok = tile < p.n_tiles && ray < p.R;
+        const int rr = ray_ok ? ray : p.R - 1;
+        const float d0 = p.raydirs[(size_t)rr * 3], d1 = p.raydirs[(size_t)rr * 3 + 1], d2 = p.raydirs[(size_t)rr * 3 + 2];
+        half8 bh[16], bl[16];
+        f32x16 acc[8];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) v[e] = sky_pe(16 * s + 8 * h + e, d0, d1, d2);
+            split8(v, bh[s], bl[s]);
+        }
+        float part = 0.f;
+        const float *nul = cst;
+        // fc1 (+ style term): 4 k-steps; fragments 0,1 of its upper half are activated behind its own tail, the
+        // remaining six (2..7) right after, the lower half behind fc2's head
+        layer8<DBG, 4, false, false, false>(lds, r, bh, bl, acc, cst + SC_BIAS1, nul, h, part);
+        act_step<2, false>(acc, nul, h, bh, bl, part);
+        act_step<3, false>(acc, nul, h, bh, bl, part);
+        act_step<4, false>(acc, nul, h, bh, bl, part);
+        act_step<5, false>(acc, nul, h, bh, bl, part);
+        act_step<6, false>(acc, nul, h, bh, bl, part);
+        act_step<7, false>(acc, nul, h, bh, bl, part);
+#pragma unroll 1
+        for (int l = 0; l < 4; l++) layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, cst + SC_BIASH + l * HID, nul, h, part);
+        f32x16 col[2];
+        col[0] = bias_block<0>(cst + SC_BC, h);
+        col[1] = bias_block<1>(cst + SC_BC, h);
+        layer_out<DBG>(lds, r, bh, bl, acc, col, nul, h, part);
+        // ---- store sky_c[ray][feature] and accumulate the per-feature sum over rays -----------------------------
+        if (ray_ok) {
+#pragma unroll
+            for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++)
+                    *reinterpret_cast<float4 *>(p.sky_c + (size_t)ray * OUTC + 32 * ib + 8 * g4 + 4 * h) =
+                        make_float4(col[ib][4 * g4], col[ib][4 * g4 + 1], col[ib][4 * g4 + 2], col[ib][4 * g4 + 3]);
+        }
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int rg = 0; rg < 16; rg++) {
+                float v = ray_ok ? col[ib][rg] : 0.f;
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                v += __shfl_xor(v, 16);      // sum over the 32 rays of this half-wave
+                if ((rg >> 2) == q) fsum[ib][rg & 3] += v;
+            }
+    }
+    // lanes with j < 4 (q = j) of each half hold the sums of features 32*ib + 8*q + 4*h + e
+    if (j < 4) {
+#pragma unroll
+        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) atomicAdd(p.sky_sum + 32 * ib + 8 * q + 4 * h + e, fsum[ib][e]);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
@@ -1097,6 +1266,38 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
         default: hipLaunchKernelGGL(mlp_kernel<0>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
     }
     return sdn::check_launch("sdn_field_mlp");
+}
+
+size_t sdn_sky_packed_weight_bytes(void) { return SKY_PACKED_FRAGS * sizeof(half8); }
+size_t sdn_sky_consts_floats(void) { return SC_TOTAL; }
+
+int sdn_sky_pack_weights(const float *w1, const float *const *wh4_host, const float *wc, void *packed, sdn_stream_t stream) {
+    SDN_REQUIRE(w1 && wh4_host && wc && packed, "sdn_sky_pack_weights: null pointer");
+    SkyPackParams p;
+    p.w1 = w1;
+    for (int i = 0; i < 4; i++) {
+        SDN_REQUIRE(wh4_host[i], "sdn_sky_pack_weights: null hidden weight");
+        p.wh[i] = wh4_host[i];
+    }
+    p.wc = wc;
+    p.out = (half8 *)packed;
+    const size_t n = 16 * 2 * 64 + 4 * 64 * 2 * 64 + 16 * 2 * 64;
+    hipLaunchKernelGGL(sky_pack_kernel, dim3((unsigned)sdn::div_up<size_t>(n, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_sky_pack_weights");
+}
+
+int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_sum, int32_t n_rays,
+                int32_t n_workgroups, sdn_stream_t stream) {
+    SDN_REQUIRE(raydirs && packed && consts && sky_c && sky_sum && n_rays > 0, "sdn_sky_mlp: bad argument");
+    SkyParams p;
+    p.raydirs = raydirs; p.wpk = (const half8 *)packed; p.consts = consts; p.sky_c = sky_c; p.sky_sum = sky_sum;
+    p.R = n_rays;
+    p.n_tiles = sdn::div_up(n_rays, 32);
+    int wg = n_workgroups > 0 ? n_workgroups : 256;
+    const int groups = sdn::div_up(p.n_tiles, 4);
+    if (wg > groups) wg = groups;
+    hipLaunchKernelGGL(sky_kernel<0>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_sky_mlp");
 }
 
 int sdn_debug_mfma_probe(const float *A, const float *B, float *C, sdn_stream_t stream) {

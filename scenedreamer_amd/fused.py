@@ -144,3 +144,34 @@ def time_encode_kernel(R, vid, d2, rd, cam_ori, ns, reps=5):
     buf = _buffers(R, n, ns)
     ms = _time_ms(lambda: encode(R, vid, d2, rd, cam_ori, ns, buf), reps)
     return n * ns, ms, 16404, "encode_kernel (collapsed 3-D table: 4096 B/sample actually gathered)"
+
+
+def prepare_sky(R):
+    """Pack the sky MLP for the current style code (fc_z_a(z) folded into fc1's bias)."""
+    lib = _lib()
+    w = R.w
+    packed = torch.empty(lib.sdn_sky_packed_weight_bytes(), dtype=torch.uint8, device=R.dev)
+    wh = [w[f"sky_net.fc{i}.weight"].contiguous() for i in (2, 3, 4, 5)]
+    ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in wh])
+    w1 = w["sky_net.fc1.weight"].contiguous()
+    wc = w["sky_net.fc_out_c.weight"].contiguous()
+    with torch.cuda.device(R.dev):
+        capi.check(lib.sdn_sky_pack_weights(w1.data_ptr(), ptrs, wc.data_ptr(), packed.data_ptr(), _stream(R.dev)))
+    consts = torch.cat([w["sky_net.fc1.bias"] + R.sky_z.reshape(-1)] + [w[f"sky_net.fc{i}.bias"] for i in (2, 3, 4, 5)] +
+                       [w["sky_net.fc_out_c.bias"]]).contiguous()
+    assert consts.numel() == lib.sdn_sky_consts_floats()
+    R._fused_sky = dict(packed=packed, consts=consts, keep=(wh, w1, wc))
+    return R._fused_sky
+
+
+def sky_fused(R, rd):
+    """sky_c [R,64] and the frame mean sky_avg [1,64] for ray directions rd [R,3]."""
+    sk = getattr(R, "_fused_sky", None) or prepare_sky(R)
+    rd = rd.contiguous()
+    n = rd.shape[0]
+    sky_c = torch.empty((n, 64), dtype=torch.float32, device=R.dev)
+    ssum = torch.zeros(64, dtype=torch.float32, device=R.dev)
+    with torch.cuda.device(R.dev):
+        capi.check(_lib().sdn_sky_mlp(rd.data_ptr(), sk["packed"].data_ptr(), sk["consts"].data_ptr(), sky_c.data_ptr(),
+                                      ssum.data_ptr(), n, 0, _stream(R.dev)), "sdn_sky_mlp")
+    return sky_c, (ssum / n).reshape(1, 64)

@@ -107,6 +107,7 @@ class Renderer:
             self.sky_z = F.linear(z, w["sky_net.fc_z_a.weight"])                         # [1, 256]
             self.cnn_adapt = F.linear(z, w["denoiser.fc_z_cond.weight"], w["denoiser.fc_z_cond.bias"])
         self._fused_style = None
+        self._fused_sky = None
 
     # ------------------------------------------------------------------ stages
     def cast_rays(self, pose, resolution_hw):
@@ -266,8 +267,12 @@ class Renderer:
             d2 = d2.view(2, R, self.M)
             rd = rd.view(R, 3)
             cam_ori = torch.as_tensor(pose[0], dtype=torch.float32).to(self.dev)
-            sky_c = self.sky_features(rd)
-            sky_avg = sky_c.mean(dim=0, keepdim=True)        # full-frame mean, scenedreamer.py:592-598
+            if mode == "fused":
+                from . import fused
+                sky_c, sky_avg = fused.sky_fused(self, rd)
+            else:
+                sky_c = self.sky_features(rd)
+                sky_avg = sky_c.mean(dim=0, keepdim=True)    # full-frame mean, scenedreamer.py:592-598
             ev.mark("sky")
             if mode == "unfused":
                 outs = []

@@ -122,3 +122,16 @@ def test_encode_matches_oracle(renderer, oracle, weights_full, lut, tag):
     wc = aux["worldcoord2"].numpy().reshape(R, ns, 3)
     nosky = (g["voxel_id"].reshape(R, M)[:, -1] != 0) | (wc[:, :, 0] <= 1.0).any(axis=1)
     np.testing.assert_array_equal(((flags >> 1) & 1).astype(bool), nosky)
+
+
+def test_sky_mlp_kernel_matches_torch(renderer):
+    """sky_kernel (PE + 6-layer MLP on MFMA + frame mean) vs posenc kernel + PyTorch fp32 GEMMs."""
+    from scenedreamer_amd import fused
+    g = golden("field_a.npz")
+    renderer.set_style_code(g["z"])
+    rd = torch.from_numpy(g["raydirs"]).cuda().reshape(-1, 3)
+    rd = torch.cat([rd, rd.flip(0)[:77]])                       # ragged count (not a multiple of 32 / 128)
+    ref = renderer.sky_features(rd)
+    got, avg = fused.sky_fused(renderer, rd)
+    assert (got - ref).abs().max().item() < 2e-4
+    assert (avg - ref.mean(dim=0, keepdim=True)).abs().max().item() < 2e-5
