@@ -145,7 +145,7 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
 /* ---------------------------------------------------------------------------
  * Render CNN: the four 3x3 256->256 convolutions of RenderCNN (conv2a/2b/3a/3b,
  * imaginaire/generators/gancraft_base.py:175-225) on MFMA with the field MLP's 3-term f16 split.
- * Activations travel between the convolutions as two f16 planes (hi, lo) [Hb*Wb][256] with a zero border
+ * Activations travel between the convolutions as two f16 planes (hi, lo) [16 chunks][Hb*Wb][16 channels] with a zero border
  * (extent from sdn_conv_plane_dims; the caller zero-fills the planes ONCE, kernels never write the border or
  * pixels outside the H x W frame); fp32 tensors are rows [H*W][256] (channels last).
  *   out = LeakyReLU_0.2( (resid + conv(in) + bias) * (mod_w + 1) + mod_b )      each term optional

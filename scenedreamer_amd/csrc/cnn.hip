@@ -3,14 +3,17 @@
 // as the field MLP (field.hip): the image must stay within 1e-3 of the fp32 reference, which plain f16 does not.
 //
 // Formulation (transposed implicit GEMM): D^T[cout][pixel] = sum_{tap, cin} W[cout][cin][tap] * X[cin][pixel + tap].
-//   * MFMA columns = 32 pixels (an 8 x 4 patch) per wave, 4 waves (a 16 x 8 patch) per workgroup;
+//   * MFMA columns = 32 pixels (an 8 x 4 patch) per wave, 8 waves (a 16 x 16 patch, 2 waves per SIMD) per workgroup;
 //     all 256 output channels of the patch live in 128 accumulator registers;
 //   * K = 9 taps x 256 channels = 144 k-steps of 16.  Per k-step a workgroup needs 16 KiB of weight fragments
 //     (shared by its 4 waves, hi + lo) and every wave 2 KiB of its own activation fragments (hi + lo):
 //     BOTH arrive by LDS-DMA.  For the activations the per-lane global address of global_load_lds is the
 //     gather (pixel + tap, 8 consecutive channels = 16 B) and the lane-linear LDS image IS the MFMA B fragment;
-//     activations are stored as two f16 planes [padded pixel][256] with a zero border, so taps need no branches;
-//   * 6-slot LDS ring (24 KiB per slot), 5 k-steps ahead, counted vmcnt + raw s_barrier per k-step exactly as
+//     activations are stored as two f16 planes laid out [16 channel chunks][padded pixel][16 channels] with a zero
+//     border (taps need no branches): for one k-step (= one chunk) a wave's 32 pixels x 32 B are four contiguous
+//     256-B runs.  (With channels-last [pixel][256] every 16-B piece sat in its own 128-B line: 8x L2->L1 read
+//     amplification, the first version of this kernel was bound by that, not by the matrix pipe.)
+//   * 5-slot LDS ring (32 KiB per slot = the whole 160 KiB LDS), 4 k-steps ahead, counted vmcnt + raw s_barrier per k-step exactly as
 //     in field.hip; because every vector-memory operation in the main loop is a DMA with the same look-ahead, no
 //     wait ever drains the pipeline (ordinary loads of B would: vmcnt completes in order);
 //   * epilogue variants: bias + LeakyReLU -> f16 planes (conv2a/3a);  residual + style FiLM + LeakyReLU ->
@@ -36,14 +39,16 @@ constexpr int CH = 256;
 constexpr int KSTEPS = 9 * 16;            // 144
 constexpr int A_BYTES = 16384;            // weight fragments of one k-step (8 row blocks, hi + lo)
 constexpr int B_BYTES = 2048;             // one wave's activation fragments of one k-step (hi + lo)
-constexpr int SLOT_BYTES = A_BYTES + 4 * B_BYTES;   // 24 KiB
-constexpr int NSLOT = 6;
-constexpr int AHEAD = 5;
-constexpr int DMA_PER_SLOT = 6;           // per wave: 4 weight pieces + 2 activation pieces
-constexpr int TILE_W = 8, TILE_H = 4;
+constexpr int WAVES = 8;                  // 2 waves per SIMD: one wave's LDS/DMA/barrier time is the other's MFMA time
+constexpr int SLOT_BYTES = A_BYTES + WAVES * B_BYTES;   // 32 KiB
+constexpr int NSLOT = 5;                  // 160 KiB = the whole LDS of a CU
+constexpr int AHEAD = 4;
+constexpr int DMA_PER_SLOT = 4;           // per wave: 2 weight pieces + 2 activation pieces
+constexpr int TILE_W = 8, TILE_H = 4;     // pixels per wave (MFMA columns)
+constexpr int PATCH_W = 16, PATCH_H = 16; // pixels per workgroup: 2 x 4 wave tiles
 
 struct ConvParams {
-    const _Float16 *xh, *xl;   // input planes [Hb*Wb][256], zero border and zero outside the frame
+    const _Float16 *xh, *xl;   // input planes [16][Hb*Wb][16], zero border and zero outside the frame
     const char *wpk;           // packed weights, KSTEPS * 16 KiB
     const float *bias;         // [256] or nullptr
     const float *resid;        // fp32 [H*W][256] or nullptr
@@ -52,7 +57,8 @@ struct ConvParams {
     _Float16 *oh, *ol;         // output planes or nullptr
     float *of32;               // fp32 [H*W][256] or nullptr
     int H, W, Hb, Wb;          // frame and padded-buffer extent (buffer pixel (y,x) -> (y+1, x+1))
-    int gx, gy, n_groups;      // workgroup patches (16 x 8 pixels)
+    long chunk_bytes;          // Hb*Wb*32: byte stride between channel chunks of a plane
+    int gx, gy, n_groups;      // workgroup patches (16 x 16 pixels)
 };
 
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
@@ -67,16 +73,14 @@ __device__ __forceinline__ float vmax(float a, float b) {
 
 // DMA of k-step `kt` of a pass into ring position `pos`
 __device__ __forceinline__ void issue_slot(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
-    // weights: this wave's 4 of the 16 1-KiB pieces
-    const char *wsrc = p.wpk + (size_t)kt * A_BYTES + wave * 4096 + lane * 16;
-    char *wdst = lds + pos * SLOT_BYTES + wave * 4096;
+    // weights: this wave's 2 of the 16 1-KiB pieces (the instruction offset applies to the global AND the LDS address)
+    const char *wsrc = p.wpk + (size_t)kt * A_BYTES + wave * 2048 + lane * 16;
+    char *wdst = lds + pos * SLOT_BYTES + wave * 2048;
     __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 3072, 0);
     // activations: tap = kt / 16 (ky = tap / 3, kx = tap % 3), channels 16*(kt % 16) + 8h .. +7 of pixel + tap
     const int tap = kt >> 4, s = kt & 15;
-    const long toff = ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * (CH * 2) + s * 32;
+    const long toff = ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * 32 + (long)s * p.chunk_bytes;
     char *bdst = lds + pos * SLOT_BYTES + A_BYTES + wave * B_BYTES;
     __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + toff), (lds_char *)bdst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xl + boff + toff), (lds_char *)(bdst + 1024), 16, 0, 0);
@@ -93,12 +97,12 @@ __device__ __forceinline__ void lds_unit(const char *slot, int u, int lane, half
 __device__ __forceinline__ long lane_pixel_offset(const ConvParams &p, int grp, int wave, int lane, int &py, int &px) {
     const int gyi = grp / p.gx, gxi = grp - gyi * p.gx;
     const int j = lane & 31, h = lane >> 5;
-    py = gyi * (2 * TILE_H) + (wave >> 1) * TILE_H + (j >> 3);
-    px = gxi * (2 * TILE_W) + (wave & 1) * TILE_W + (j & 7);
-    return ((long)(py + 1) * p.Wb + (px + 1)) * (CH * 2) + h * 16;
+    py = gyi * PATCH_H + (wave >> 1) * TILE_H + (j >> 3);
+    px = gxi * PATCH_W + (wave & 1) * TILE_W + (j & 7);
+    return ((long)(py + 1) * p.Wb + (px + 1)) * 32 + h * 16;   // byte offset inside chunk 0
 }
 
-__global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
+__global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[NSLOT * SLOT_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -119,10 +123,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
         pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
     }
 
-    // Fragment registers: a[u] = weight unit u of the current k-step (4 x 16 B each), bh/bl = this wave's
-    // activation fragments.  Units 0,1 and the activations of k-step kt+1 are fetched from LDS during units 2,3 of
-    // k-step kt (slot kt+1 is complete at the barrier of kt), so no k-step starts with an exposed LDS round trip.
-    half8 a[4][4];
+    // Fragment registers: two weight units (current, next) and this wave's activation fragments.  With two waves
+    // per SIMD the other wave covers LDS latency, so one unit of look-ahead is enough (registers: 128 accumulators
+    // + 32 + 16 must stay <= 256 per wave).
+    half8 a[2][4];
     half8 bh, bl;
     bool primed = false;
 
@@ -144,7 +148,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
             const char *slot_n = lds + pos_use * SLOT_BYTES;
             if (!primed) {   // very first k-step of the kernel only
                 lds_unit(slot, 0, lane, a[0]);
-                lds_unit(slot, 1, lane, a[1]);
                 bh = *reinterpret_cast<const half8 *>(slot + A_BYTES + wave * B_BYTES + lane * 16);
                 bl = *reinterpret_cast<const half8 *>(slot + A_BYTES + wave * B_BYTES + 1024 + lane * 16);
                 primed = true;
@@ -153,29 +156,28 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int ib = 2 * u;
-                if (kt == 0) {
-                    f32x16 z;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) z[r] = 0.f;
-                    acc[ib] = mfma16(a[u][0], bh, z);
-                    acc[ib + 1] = mfma16(a[u][2], bh, z);
-                } else {
-                    acc[ib] = mfma16(a[u][0], bh, acc[ib]);
-                    acc[ib + 1] = mfma16(a[u][2], bh, acc[ib + 1]);
-                }
-                acc[ib] = mfma16(a[u][1], bh, acc[ib]);
-                acc[ib + 1] = mfma16(a[u][3], bh, acc[ib + 1]);
-                acc[ib] = mfma16(a[u][0], bl, acc[ib]);
-                acc[ib + 1] = mfma16(a[u][2], bl, acc[ib + 1]);
-                // prefetch two units ahead: units 2,3 of this slot, then units 0,1 (+ activations) of the next slot
-                if (u == 0) lds_unit(slot, 2, lane, a[2]);
-                if (u == 1) lds_unit(slot, 3, lane, a[3]);
-                if (u == 2) {
+                half8(&au)[4] = a[u & 1];
+                // next unit (of this slot, or unit 0 + activations of the next slot, complete since this barrier)
+                if (u < 3) lds_unit(slot, u + 1, lane, a[(u + 1) & 1]);
+                else {
                     lds_unit(slot_n, 0, lane, a[0]);
                     bh_n = *reinterpret_cast<const half8 *>(slot_n + A_BYTES + wave * B_BYTES + lane * 16);
                     bl_n = *reinterpret_cast<const half8 *>(slot_n + A_BYTES + wave * B_BYTES + 1024 + lane * 16);
                 }
-                if (u == 3) lds_unit(slot_n, 1, lane, a[1]);
+                if (kt == 0) {
+                    f32x16 z;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) z[r] = 0.f;
+                    acc[ib] = mfma16(au[0], bh, z);
+                    acc[ib + 1] = mfma16(au[2], bh, z);
+                } else {
+                    acc[ib] = mfma16(au[0], bh, acc[ib]);
+                    acc[ib + 1] = mfma16(au[2], bh, acc[ib + 1]);
+                }
+                acc[ib] = mfma16(au[1], bh, acc[ib]);
+                acc[ib + 1] = mfma16(au[3], bh, acc[ib + 1]);
+                acc[ib] = mfma16(au[0], bl, acc[ib]);
+                acc[ib + 1] = mfma16(au[2], bl, acc[ib + 1]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             bh = bh_n;
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
         const bool in_frame = py < p.H && px < p.W;
         if (in_frame) {
             const long orow = (long)py * p.W + px;                          // fp32 rows are unpadded
-            const long prow = ((long)(py + 1) * p.Wb + (px + 1)) * CH;      // planes are padded
+            const long ppix = (long)(py + 1) * p.Wb + (px + 1);             // padded pixel index
 #pragma unroll
             for (int ib = 0; ib < 8; ib++) {
 #pragma unroll
@@ -217,8 +219,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(const ConvParams p) {
                         half4 hv, lv;
                         hv[0] = (_Float16)h0[0]; hv[1] = (_Float16)h0[1]; hv[2] = (_Float16)h1[0]; hv[3] = (_Float16)h1[1];
                         lv[0] = (_Float16)l0[0]; lv[1] = (_Float16)l0[1]; lv[2] = (_Float16)l1[0]; lv[3] = (_Float16)l1[1];
-                        *reinterpret_cast<half4 *>(p.oh + prow + c0) = hv;
-                        *reinterpret_cast<half4 *>(p.ol + prow + c0) = lv;
+                        const long po = ((long)(c0 >> 4) * ((long)p.Hb * p.Wb) + ppix) * 16 + (c0 & 15);
+                        *reinterpret_cast<half4 *>(p.oh + po) = hv;
+                        *reinterpret_cast<half4 *>(p.ol + po) = lv;
                     }
                 }
             }
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict_
 
 // ---- fp32 rows [H*W][256] -> padded f16 hi / lo planes ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void planes_kernel(const float *__restrict__ x, _Float16 *__restrict__ oh,
-                                                     _Float16 *__restrict__ ol, int H, int W, int Wb) {
+                                                     _Float16 *__restrict__ ol, int H, int W, int Hb, int Wb) {
     const long n = (long)H * W * (CH / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const long pix = i / (CH / 4);
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256) void planes_kernel(const float *__restrict__ x
         half4 hv, lv;
         hv[0] = (_Float16)h0[0]; hv[1] = (_Float16)h0[1]; hv[2] = (_Float16)h1[0]; hv[3] = (_Float16)h1[1];
         lv[0] = (_Float16)l0[0]; lv[1] = (_Float16)l0[1]; lv[2] = (_Float16)l1[0]; lv[3] = (_Float16)l1[1];
-        const long o = ((long)(y + 1) * Wb + (xx + 1)) * CH + c0;
+        const long o = ((long)(c0 >> 4) * ((long)Hb * Wb) + (long)(y + 1) * Wb + (xx + 1)) * 16 + (c0 & 15);
         *reinterpret_cast<half4 *>(oh + o) = hv;
         *reinterpret_cast<half4 *>(ol + o) = lv;
     }
@@ -285,10 +288,10 @@ __global__ __launch_bounds__(256) void planes_kernel(const float *__restrict__ x
 
 extern "C" {
 
-// padded plane extent for an H x W frame: multiples of the 16 x 8 workgroup patch + 1-pixel zero border
+// padded plane extent for an H x W frame: multiples of the 16 x 16 workgroup patch + 1-pixel zero border
 void sdn_conv_plane_dims(int H, int W, int *Hb, int *Wb) {
-    *Hb = sdn::div_up(H, 2 * TILE_H) * 2 * TILE_H + 2;
-    *Wb = sdn::div_up(W, 2 * TILE_W) * 2 * TILE_W + 2;
+    *Hb = sdn::div_up(H, PATCH_H) * PATCH_H + 2;
+    *Wb = sdn::div_up(W, PATCH_W) * PATCH_W + 2;
 }
 
 size_t sdn_conv_packed_weight_bytes(void) { return (size_t)KSTEPS * A_BYTES; }
@@ -306,7 +309,7 @@ int sdn_conv_planes_from_f32(const float *x, void *out_hi, void *out_lo, int H, 
     int Hb, Wb;
     sdn_conv_plane_dims(H, W, &Hb, &Wb);
     hipLaunchKernelGGL(planes_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, (_Float16 *)out_hi, (_Float16 *)out_lo,
-                       H, W, Wb);
+                       H, W, Hb, Wb);
     return sdn::check_launch("sdn_conv_planes_from_f32");
 }
 
@@ -322,12 +325,13 @@ int sdn_conv3x3(const void *in_hi, const void *in_lo, const void *packed, const 
     p.oh = (_Float16 *)out_hi; p.ol = (_Float16 *)out_lo; p.of32 = out_f32;
     p.H = H; p.W = W;
     sdn_conv_plane_dims(H, W, &p.Hb, &p.Wb);
-    p.gx = sdn::div_up(W, 2 * TILE_W);
-    p.gy = sdn::div_up(H, 2 * TILE_H);
+    p.chunk_bytes = (long)p.Hb * p.Wb * 32;
+    p.gx = sdn::div_up(W, PATCH_W);
+    p.gy = sdn::div_up(H, PATCH_H);
     p.n_groups = p.gx * p.gy;
     int wg = n_workgroups > 0 ? n_workgroups : 256;
     if (wg > p.n_groups) wg = p.n_groups;
-    hipLaunchKernelGGL(conv3x3_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(conv3x3_kernel, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_conv3x3");
 }
 
