@@ -25,7 +25,7 @@ SOURCES = {
     "posenc.hip": [],
     "gridenc.hip": [],
     "field.hip": (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
-    "cnn.hip": [],
+    "cnn.hip": (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -78,8 +78,10 @@ __device__ __forceinline__ void issue_slot(char *lds, const ConvParams &p, int p
     char *wdst = lds + pos * SLOT_BYTES + wave * 2048;
     __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 1024, 0);
-    // activations: tap = kt / 16 (ky = tap / 3, kx = tap % 3), channels 16*(kt % 16) + 8h .. +7 of pixel + tap
-    const int tap = kt >> 4, s = kt & 15;
+    // k order is channel-chunk major: kt = 9*s + tap.  The 9 taps of one 16-channel chunk re-read the same
+    // (patch + halo) x 32 B region, which stays in L1/L2; with tap-major order every tap re-streamed the whole patch
+    // from the Infinity Cache (measured 3.2 GB fetched per launch for 0.58 GB of input).
+    const int s = kt / 9, tap = kt - 9 * s;
     const long toff = ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * 32 + (long)s * p.chunk_bytes;
     char *bdst = lds + pos * SLOT_BYTES + A_BYTES + wave * B_BYTES;
     __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + toff), (lds_char *)bdst, 16, 0, 0);
@@ -102,6 +104,7 @@ __device__ __forceinline__ long lane_pixel_offset(const ConvParams &p, int grp, 
     return ((long)(py + 1) * p.Wb + (px + 1)) * 32 + h * 16;   // byte offset inside chunk 0
 }
 
+template <int DBG>
 __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[NSLOT * SLOT_BYTES];
     const int lane = threadIdx.x & 63;
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
         for (int kt = 0; kt < KSTEPS; kt++) {
             // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free -----
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
-            __builtin_amdgcn_s_barrier();
-            {
+            if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+            if constexpr (!(DBG & 1)) {
                 const int qn = kt + AHEAD;   // k-step to fetch, possibly of the next patch
                 if (qn < KSTEPS) issue_slot(lds, p, pos_issue, qn, wave, lane, boff);
                 else issue_slot(lds, p, pos_issue, qn - KSTEPS, wave, lane, boff_n);
@@ -164,6 +167,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
                     bh_n = *reinterpret_cast<const half8 *>(slot_n + A_BYTES + wave * B_BYTES + lane * 16);
                     bl_n = *reinterpret_cast<const half8 *>(slot_n + A_BYTES + wave * B_BYTES + 1024 + lane * 16);
                 }
+                if constexpr (DBG & 16) {
+                    asm volatile("" ::"v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]), "v"(bh), "v"(bl));
+                    if (kt == 0) for (int r = 0; r < 16; r++) { acc[ib][r] = 0.f; acc[ib + 1][r] = 0.f; }
+                } else {
                 if (kt == 0) {
                     f32x16 z;
 #pragma unroll
@@ -178,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
                 acc[ib + 1] = mfma16(au[3], bh, acc[ib + 1]);
                 acc[ib] = mfma16(au[0], bl, acc[ib]);
                 acc[ib + 1] = mfma16(au[2], bl, acc[ib + 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             bh = bh_n;
@@ -239,14 +247,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
     __builtin_amdgcn_s_barrier();
 }
 
-// ---- weight packing: W [256][256][3][3] (PyTorch OIHW) -> [k-step t = tap*16 + s][unit][frag][64 lanes][8] ------------
+// ---- weight packing: W [256][256][3][3] (PyTorch OIHW) -> [k-step t = 9*s + tap][unit][frag][64 lanes][8] ------------
 __global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict__ W, half8 *__restrict__ out) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // (t, ib, lane)
     if (g >= (size_t)KSTEPS * 8 * 64) return;
     const int lane = (int)(g % 64);
     const int ib = (int)((g / 64) % 8);
     const int t = (int)(g / (64 * 8));
-    const int tap = t >> 4, s = t & 15;
+    const int s = t / 9, tap = t - 9 * s;   // same k order as issue_slot
     const int co = 32 * ib + (lane & 31), h = lane >> 5;
     half8 hi, lo;
 #pragma unroll
@@ -331,7 +339,20 @@ int sdn_conv3x3(const void *in_hi, const void *in_lo, const void *packed, const 
     p.n_groups = p.gx * p.gy;
     int wg = n_workgroups > 0 ? n_workgroups : 256;
     if (wg > p.n_groups) wg = p.n_groups;
-    hipLaunchKernelGGL(conv3x3_kernel, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
+    static const int dbg = [] {
+        const char *e = getenv("SDN_CONV_DBG");   // timing experiments only; results are wrong unless 0
+        return e ? atoi(e) : 0;
+    }();
+    switch (dbg) {
+#ifdef SDN_MLP_ABLATION
+        case 1: hipLaunchKernelGGL(conv3x3_kernel<1>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL(conv3x3_kernel<2>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 3: hipLaunchKernelGGL(conv3x3_kernel<3>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 16: hipLaunchKernelGGL(conv3x3_kernel<16>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 19: hipLaunchKernelGGL(conv3x3_kernel<19>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+#endif
+        default: hipLaunchKernelGGL(conv3x3_kernel<0>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+    }
     return sdn::check_launch("sdn_conv3x3");
 }
 
