@@ -52,6 +52,14 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "camera_pattern0.npz"), scene_S=SCENE_S, scene_seed=SCENE_SEED, maxstep=8,
                         ori=np.stack([p[0] for p in poses]), dir=np.stack([p[1] for p in poses]),
                         up=np.stack([p[2] for p in poses]), f=np.asarray([p[3] for p in poses], np.float64))
+    allp = {}
+    for pat in range(10):   # all ten EvalCameraController trajectories
+        c = camctl.EvalCameraController(G.voxel, maxstep=8, pattern=pat, cam_ang=72, smooth_decay_multiplier=150 / 8)
+        allp[f"ori{pat}"] = np.stack([np.asarray(q[0], np.float32) for q in c])
+        allp[f"dir{pat}"] = np.stack([np.asarray(q[1], np.float32) for q in c])
+        allp[f"up{pat}"] = np.stack([np.asarray(q[2], np.float32) for q in c])
+        allp[f"f{pat}"] = np.asarray([float(q[3]) for q in c], np.float64)
+    np.savez_compressed(os.path.join(GOLD, "camera_patterns.npz"), scene_S=SCENE_S, scene_seed=SCENE_SEED, maxstep=8, **allp)
 
     # ---- per-trajectory constants ---------------------------------------------------------------
     style = torch.from_numpy(synth.make_style(Z_SEED))

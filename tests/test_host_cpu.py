@@ -24,18 +24,33 @@ def test_camera_poses_match_reference_controller(scene256):
         assert f == g["f"][i]
 
 
+def test_all_ten_camera_patterns_match_reference(scene256):
+    from scenedreamer_amd import camera
+    g = golden("camera_patterns.npz")
+    for pat in range(10):
+        poses = camera.eval_camera_poses(scene256, maxstep=int(g["maxstep"]), pattern=pat)
+        for i, (o, d, u, f) in enumerate(poses):
+            np.testing.assert_array_equal(o.numpy(), g[f"ori{pat}"][i])
+            np.testing.assert_array_equal(d.numpy(), g[f"dir{pat}"][i])
+            np.testing.assert_array_equal(u.numpy(), g[f"up{pat}"][i])
+            assert float(f) == g[f"f{pat}"][i]
+    with pytest.raises(ValueError):
+        camera.eval_camera_poses(scene256, maxstep=4, pattern=10)
+
+
 @pytest.mark.needs_reference
 def test_camera_poses_match_live_reference(scene256):
     from oracle import ref_harness as RH
     RH.install("oracle")
     import imaginaire.model_utils.gancraft.camctl as camctl
     from scenedreamer_amd import camera
-    ctl = camctl.EvalCameraController(scene256, maxstep=12, pattern=0, cam_ang=72, smooth_decay_multiplier=150 / 12)
-    mine = camera.eval_camera_poses(scene256, maxstep=12)
-    for a, b in zip(ctl, mine):
-        for x, y in zip(a[:3], b[:3]):
-            np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
-        assert a[3] == b[3]
+    for pat in range(10):
+        ctl = camctl.EvalCameraController(scene256, maxstep=12, pattern=pat, cam_ang=72, smooth_decay_multiplier=150 / 12)
+        mine = camera.eval_camera_poses(scene256, maxstep=12, pattern=pat)
+        for a, b in zip(ctl, mine):
+            for x, y in zip(a[:3], b[:3]):
+                np.testing.assert_array_equal(np.asarray(x), np.asarray(y))
+            assert float(a[3]) == float(b[3])
 
 
 def test_tile_grid_and_intrinsics():
