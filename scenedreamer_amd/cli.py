@@ -1,0 +1,72 @@
+"""Trajectory renderer with the reference's inference.py / inference_givenstyle interface
+(inference.py:18-32, configs/scenedreamer_inference.yaml:1-17):
+
+    python -m scenedreamer_amd.cli --output_dir out --seed 8888 [--checkpoint scenedreamer_released.pt]
+        [--camera_mode 4 --cam_maxstep 40 --resolution_hw 540 960 --num_samples 40 --cam_ang 72 --scene_size 2048]
+    python -m torch.distributed.run --nproc-per-node N ... -m scenedreamer_amd.cli ...     # frames sharded over GPUs
+
+Without --checkpoint (none is available offline) a seeded synthetic scene and random-init weights of the reference's
+shapes are used.  Frames are written as <output_dir>/rgb_render/%05d.png by a background writer."""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--output_dir", required=True)
+    ap.add_argument("--seed", type=int, default=8888)
+    ap.add_argument("--checkpoint", default="")
+    ap.add_argument("--camera_mode", type=int, default=4)
+    ap.add_argument("--cam_maxstep", type=int, default=40)
+    ap.add_argument("--resolution_hw", type=int, nargs=2, default=[540, 960])
+    ap.add_argument("--num_samples", type=int, default=40)
+    ap.add_argument("--cam_ang", type=float, default=72)
+    ap.add_argument("--scene_size", type=int, default=2048)
+    ap.add_argument("--mode", default="fused", choices=["fused", "unfused"])
+    args = ap.parse_args()
+
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", 1), ("RANK", 0), ("LOCAL_RANK", 0)))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method="env://")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from . import camera, synth
+    from . import dist as sdist
+    from .output import FrameWriter
+    from .renderer import Renderer
+
+    scene = weights = style = None
+    if rank == 0:
+        scene = synth.make_scene(args.scene_size, 3407, device=dev)
+        if args.checkpoint:
+            ck = torch.load(args.checkpoint, map_location="cpu")      # inference.py:57-61 ("module." prefix)
+            weights = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ck["net_G"].items()}
+        else:
+            weights = synth.make_weights(0)
+        style = synth.make_style(args.seed)                           # inference.py:81-82
+    if world > 1:
+        scene, weights, style = sdist.broadcast_state(scene, weights, style, dev, src=0)
+    R = Renderer(weights, scene, dev)
+    R.set_style(style)
+    poses = camera.eval_camera_poses(scene, maxstep=args.cam_maxstep, pattern=args.camera_mode, cam_ang=args.cam_ang)
+    out = os.path.join(args.output_dir, "rgb_render")
+    writer = FrameWriter(out)
+    if rank == 0:
+        np.save(os.path.join(out, "style.npy"), np.asarray(style))    # scenedreamer.py:564
+    for f in sdist.shard_frames(range(len(poses)), rank, world):
+        print(f"[rank {rank}] Rendering frame {f}", flush=True)
+        img = R.render_frame(poses[f], tuple(args.resolution_hw), args.num_samples, mode=args.mode)
+        writer.submit(img, f)
+    writer.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

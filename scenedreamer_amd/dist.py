@@ -103,3 +103,42 @@ def broadcast_state(scene, weights, style, dev, src=0):
     sc.sample_size = int(sc.voxel_t.shape[1])
     w = {k[2:]: v for k, v in got.items() if k.startswith("w:")}
     return sc, w, got["z:style"].cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Tile-parallel rendering of ONE frame (BASELINE.json config 5: 3840x2160 over 8 GPUs)
+# --------------------------------------------------------------------------------------------------------------
+def row_bands(height, world):
+    """Contiguous output-row bands, one per rank: [(row0, row1)] * world."""
+    return [(height * k // world, height * (k + 1) // world) for k in range(world)]
+
+
+def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode="fused", group=None):
+    """Every rank renders one row band of the frame (with the CNN's 15-px apron, the same overlap the reference's tiles
+    use); the only exchange step of the path is the frame-wide sky mean: all_reduce(sum) of 64+1 numbers.  Rank 0
+    receives the stitched image [1,3,H,W]; the other ranks return None.
+
+    `renderer` needs band_prepare(pose, hw, row0, row1, mode) -> {"sky_sum" f64[64], "sky_cnt" int, ...} and
+    band_finish(handle, sky_avg[1,64], num_samples) -> image rows; scenedreamer_amd.renderer.Renderer provides both."""
+    world = dist.get_world_size(group) if _is_init() else 1
+    rank = dist.get_rank(group) if _is_init() else 0
+    H, W = resolution_hw
+    bands = row_bands(H, world)
+    row0, row1 = bands[rank]
+    hd = renderer.band_prepare(pose, resolution_hw, row0, row1, mode)
+    red = torch.cat([hd["sky_sum"].to(torch.float64).reshape(64),
+                     torch.tensor([float(hd["sky_cnt"])], dtype=torch.float64, device=hd["sky_sum"].device)])
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
+    sky_avg = (red[:64] / red[64]).to(torch.float32).reshape(1, 64)
+    img = renderer.band_finish(hd, sky_avg, num_samples)
+    if world == 1:
+        return img
+    hmax = max(b[1] - b[0] for b in bands)
+    pad = torch.zeros((1, 3, hmax, W), dtype=img.dtype, device=img.device)
+    pad[:, :, :img.shape[2]] = img
+    outs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, outs, dst=0, group=group)
+    if rank != 0:
+        return None
+    return torch.cat([o[:, :, :b[1] - b[0]] for o, b in zip(outs, bands)], dim=2)

@@ -252,6 +252,57 @@ class Renderer:
                        "algorithmic product (hi*hi + lo*hi + hi*lo) and skips 32-ray groups that hit nothing"}
         return mlp, grid
 
+    # ------------------------------------------------------------------ row bands (tile-parallel single frame)
+    def band_prepare(self, pose, resolution_hw, row0, row1, mode="fused"):
+        """Cast the rays needed for output rows [row0,row1) (padded rows [row0, row1+pad)) and evaluate the sky MLP.
+        Returns a handle with the band's share of the frame-wide sky sum: padded rows [row0,row1) are owned by this
+        band, the band that ends the frame also owns the trailing `pad` rows, so every ray is counted exactly once
+        (sky_avg is the mean over ALL rays of the padded frame, scenedreamer.py:592-598)."""
+        cam_ori, cam_dir, cam_up, cam_f = pose
+        H, W = resolution_hw
+        f, c, cam_res = frame_intrinsics(cam_f, resolution_hw, self.pad)
+        p0, p1 = row0, row1 + self.pad
+        # same rays as the full frame: ndc_y = c0 - row_global = (c0 - p0) - row_local, exact in float32
+        vid, d2, rd = ops.ray_voxel_intersection_perspective(self.voxel_t, cam_ori, cam_dir, cam_up, f, [c[0] - p0, c[1]],
+                                                             [p1 - p0, cam_res[1]], self.M)
+        Wp = cam_res[1]
+        n = (p1 - p0) * Wp
+        vid, d2, rd = vid.view(n, self.M), d2.view(2, n, self.M), rd.view(n, 3)
+        with torch.no_grad():
+            if mode == "fused":
+                from . import fused
+                sky_c, _ = fused.sky_fused(self, rd)
+            else:
+                sky_c = self.sky_features(rd)
+            own1 = (row1 - row0 + (self.pad if row1 == H else 0)) * Wp
+            sky_sum = sky_c[:own1].sum(dim=0, dtype=torch.float64)
+        return dict(vid=vid, d2=d2, rd=rd, sky_c=sky_c, sky_sum=sky_sum, sky_cnt=own1, rows=(p1 - p0), Wp=Wp,
+                    cam_ori=torch.as_tensor(cam_ori, dtype=torch.float32).to(self.dev), mode=mode)
+
+    def band_finish(self, hd, sky_avg, num_samples, cnn_mode=None):
+        """Field + CNN for a prepared band given the frame-wide sky_avg [1,64]; returns image rows [1,3,row1-row0,W]."""
+        mode = hd["mode"]
+        with torch.no_grad():
+            sky_avg = sky_avg.to(torch.float32).reshape(1, 64)
+            if mode == "fused":
+                from . import fused
+                net_out = fused.field_fused(self, hd["vid"], hd["d2"], hd["rd"], hd["cam_ori"], hd["sky_c"], sky_avg,
+                                            num_samples)
+            else:
+                net_out = self.field_unfused(hd["vid"], hd["d2"], hd["rd"], hd["cam_ori"], hd["sky_c"], sky_avg, num_samples)
+            net_out = net_out.view(1, hd["rows"], hd["Wp"], 64)
+            if cnn_mode is None:
+                cnn_mode = "mfma" if mode == "fused" else "torch"
+            if cnn_mode == "mfma":
+                if getattr(self, "_mfma_cnn", None) is None:
+                    from .cnn import MfmaCNN
+                    self._mfma_cnn = MfmaCNN(self)
+                img = self._mfma_cnn(net_out)
+            else:
+                img = self.render_cnn(net_out)
+            p = self.pad // 2
+            return img[:, :, p:-p, p:-p] if self.pad else img
+
     # ------------------------------------------------------------------ frame
     def render_frame(self, pose, resolution_hw=(540, 960), num_samples=24, mode="unfused", cnn=True,
                      ray_chunk=1 << 16, timers=None, cnn_mode=None):

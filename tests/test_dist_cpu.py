@@ -69,3 +69,57 @@ def test_checksum_detects_corruption():
     b = a.clone()
     b[17] += 1
     assert sdist.checksum(a) != sdist.checksum(b) and sdist.checksum(a) == sdist.checksum(a.clone())
+
+
+class _FakeRenderer:
+    """Stands in for Renderer in the orchestration test: sky feature of a ray = f(global padded row), image row
+    value = global row index + frame-wide sky mean, so any band/ownership/stitching mistake changes the result."""
+    pad = 30
+
+    def __init__(self, H, W):
+        self.H, self.W = H, W
+
+    def band_prepare(self, pose, hw, row0, row1, mode):
+        H, W = hw
+        Wp = W + self.pad
+        rows = torch.arange(row0, row1 + self.pad, dtype=torch.float64)
+        sky_c = (rows[:, None, None] * 0.01 + torch.arange(64, dtype=torch.float64)[None, None, :]).expand(-1, Wp, -1).reshape(-1, 64)
+        own = (row1 - row0 + (self.pad if row1 == H else 0)) * Wp
+        return dict(sky_sum=sky_c[:own].sum(0), sky_cnt=own, rows=(row0, row1))
+
+    def band_finish(self, hd, sky_avg, ns):
+        r0, r1 = hd["rows"]
+        img = torch.arange(r0, r1, dtype=torch.float32)[None, None, :, None].expand(1, 3, -1, self.W).clone()
+        return img + sky_avg.reshape(-1)[:3].to(torch.float32)[None, :, None, None]
+
+
+def _tp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from scenedreamer_amd import dist as sdist
+        H, W = 37, 20          # ragged: 37 rows over 2 ranks -> 18 + 19
+        img = sdist.render_frame_tile_parallel(_FakeRenderer(H, W), None, (H, W), 4)
+        q.put((rank, None if img is None else img.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tile_parallel_single_frame_world2():
+    from scenedreamer_amd import dist as sdist
+    H, W = 37, 20
+    single = sdist.render_frame_tile_parallel(_FakeRenderer(H, W), None, (H, W), 4).numpy()   # no process group: world 1
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[1] is None and res[0].shape == (1, 3, H, W)
+    np.testing.assert_allclose(res[0], single, rtol=0, atol=1e-6)
+    assert sdist.row_bands(37, 2) == [(0, 18), (18, 37)] and sdist.row_bands(2160, 8)[-1] == (1890, 2160)

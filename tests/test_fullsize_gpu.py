@@ -1,0 +1,77 @@
+"""BASELINE.json's full sizes on the MI355X, through size-independent properties (the CPU oracle is too slow there):
+ray-marcher invariants checked against the volume itself, and agreement of two independent implementations
+(fused HIP field + MFMA CNN  vs  drop-in ops + PyTorch glue) on whole frames."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    from scenedreamer_amd import camera, synth
+    from scenedreamer_amd.renderer import Renderer
+    scene = synth.make_scene(2048, 3407, device="cuda")
+    R = Renderer(synth.make_weights(0), scene, "cuda")
+    R.set_style(synth.make_style(8888))
+    poses = camera.eval_camera_poses(scene, maxstep=40)
+    return R, scene, poses
+
+
+@pytest.mark.parametrize("hw", [(540, 960), (1080, 1920)])
+def test_rvip_invariants_at_full_size(big, hw):
+    R, scene, poses = big
+    vox = scene.voxel_t
+    for pi in (0, 7, 20):            # pose 0 sits on the volume boundary (out-of-bounds `continue` branch)
+        pose = poses[pi]
+        vid, d2, rd, cam_res = R.cast_rays(pose, hw)
+        vid2, d22, _, _ = R.cast_rays(pose, hw)
+        assert torch.equal(vid, vid2) and torch.equal(d2.nan_to_num(-1), d22.nan_to_num(-1))     # deterministic
+        n = cam_res[0] * cam_res[1]
+        vid, t, t2, rd = vid.view(n, 6), d2[0].view(n, 6), d2[1].view(n, 6), rd.view(n, 3)
+        hit = vid != 0
+        assert torch.equal(torch.isnan(t), ~hit) and torch.equal(torch.isnan(t2), ~hit)              # NaN <=> miss
+        assert bool((hit[:, 1:] <= hit[:, :-1]).all())                                                # hits are a prefix
+        assert bool((t2[hit] >= t[hit]).all()) and bool((t[hit] >= 0).all())
+        both = hit[:, 1:] & hit[:, :-1]
+        assert bool((t[:, 1:][both] >= t2[:, :-1][both]).all())                                       # ordered along the ray
+        assert float((rd.norm(dim=1) - 1).abs().max()) < 1e-6
+        # the midpoint of every recorded segment lies inside a voxel that carries the recorded id
+        ori = torch.as_tensor(pose[0], dtype=torch.float32, device="cuda")
+        mid = ((t + t2) * 0.5).unsqueeze(-1)
+        p = torch.floor(ori + rd.unsqueeze(1) * mid.nan_to_num(0)).long()
+        inb = hit & (p[..., 0] >= 0) & (p[..., 0] < vox.shape[0]) & (p[..., 1] >= 0) & (p[..., 1] < vox.shape[1]) & \
+            (p[..., 2] >= 0) & (p[..., 2] < vox.shape[2])
+        assert inb.sum() >= 0.999 * hit.sum()
+        got = vox[p[..., 0][inb], p[..., 1][inb], p[..., 2][inb]]
+        assert float((got == vid[inb]).float().mean()) > 0.9999                                       # fp slack on edges
+        assert int(hit.sum()) > 0.3 * n
+
+
+@pytest.mark.parametrize("hw,ns,pi", [((540, 960), 24, 4), ((1080, 1920), 40, 12)])
+def test_fused_and_unfused_frames_agree_at_full_size(big, hw, ns, pi):
+    R, scene, poses = big
+    a = R.render_frame(poses[pi], hw, ns, mode="fused")
+    b = R.render_frame(poses[pi], hw, ns, mode="unfused", cnn_mode="torch")
+    assert a.shape == (1, 3, hw[0], hw[1])
+    err = (a - b).abs()
+    assert float(err.max()) < 1e-3, f"max abs diff {float(err.max()):.3e}"
+    assert float(a.std()) > 0.05 and bool(torch.isfinite(a).all())
+
+
+def test_config1_frame_against_cpu_oracle(lut):
+    """BASELINE.json configs[0]: 128x128, 12 samples, scene_size 1024 -- one whole frame vs the CPU oracle."""
+    from oracle import field_ref as FR
+    from scenedreamer_amd import camera, synth
+    from scenedreamer_amd.renderer import Renderer
+    scene = synth.make_scene(1024, 3407)
+    w = synth.make_weights(0)
+    R = Renderer(w, scene, "cuda")
+    R.set_style(synth.make_style(8888))
+    pose = camera.eval_camera_poses(scene, maxstep=40)[6]
+    img = R.render_frame(pose, (128, 128), 12, mode="fused")
+    ref = FR.render_frame_tiled(w, lut, scene.voxel_t.numpy(), (pose[0].numpy(), pose[1].numpy(), pose[2].numpy(), pose[3]),
+                                (128, 128), 12, R.z.cpu().numpy(), R.global_enc.cpu().numpy())
+    err = np.abs(img.cpu().numpy() - ref.numpy())
+    assert err.max() < 1e-3, f"max abs err {err.max():.3e}"

@@ -174,3 +174,21 @@ def test_shims_are_importable():
     enc = gridencoder.GridEncoder(input_dim=5, desired_resolution=2048, level_dim=8, log2_hashmap_size=8)
     assert enc.output_dim == 128 and tuple(enc.embeddings.shape) == (16 * 256, 8)
     assert "embeddings" in enc.state_dict() and "offsets" in enc.state_dict()
+
+
+def test_frame_writer_roundtrip(tmp_path):
+    from scenedreamer_amd.output import FrameWriter, to_uint8_hwc
+    img = torch.linspace(-1, 1, 3 * 6 * 8).reshape(1, 3, 6, 8)
+    ref = ((img * 0.5 + 0.5) * 255).numpy().astype(np.uint8)[0].transpose(1, 2, 0)     # scenedreamer.py:513
+    np.testing.assert_array_equal(to_uint8_hwc(img).numpy(), ref)
+    w = FrameWriter(str(tmp_path), fmt="png")
+    for i in range(3):
+        w.submit(img, i)
+    w.close()
+    files = sorted(os.listdir(tmp_path))
+    assert len(files) == 3
+    if files[0].endswith(".png"):
+        from PIL import Image
+        np.testing.assert_array_equal(np.asarray(Image.open(os.path.join(tmp_path, files[1]))), ref)
+    else:
+        np.testing.assert_array_equal(np.load(os.path.join(tmp_path, files[1])), ref)
