@@ -143,22 +143,27 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
                   int32_t n_workgroups, sdn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
- * Render CNN: the four 3x3 256->256 convolutions of RenderCNN (conv2a/2b/3a/3b,
- * imaginaire/generators/gancraft_base.py:175-225) on MFMA with the field MLP's 3-term f16 split.
- * Activations travel between the convolutions as two f16 planes (hi, lo) [16 chunks][Hb*Wb][16 channels] with a zero border
- * (extent from sdn_conv_plane_dims; the caller zero-fills the planes ONCE, kernels never write the border or
+ * Render CNN: the convolutions of RenderCNN (imaginaire/generators/gancraft_base.py:175-225, forward :202-225) on MFMA
+ * with the field MLP's 3-term f16 split: 3x3 256->256 (conv2a/2b/3a/3b; taps = 9, cin = 256) and 1x1 cin->256
+ * (conv1 64->256, conv4a/4b; taps = 1); the final conv4 (256->3, 1x1) + tanh (:221, :603) is an optional projection
+ * in the epilogue.
+ * Activations travel between the convolutions as two f16 planes (hi, lo) [cin/16 chunks][Hb*Wb][16 channels] with a zero
+ * border (extent from sdn_conv_plane_dims; the caller zero-fills the planes ONCE, kernels never write the border or
  * pixels outside the H x W frame); fp32 tensors are rows [H*W][256] (channels last).
- *   out = LeakyReLU_0.2( (resid + conv(in) + bias) * (mod_w + 1) + mod_b )      each term optional
+ *   y   = LeakyReLU_0.2( (resid + conv(in) + bias) * (mod_w + 1) + mod_b )       each term optional
+ *   img = tanh(proj_w . y + proj_b)                                                optional, [3][H*W]
  */
 void sdn_conv_plane_dims(int H, int W, int *Hb, int *Wb);
-size_t sdn_conv_packed_weight_bytes(void);
-/* w_oihw dev f32 [256,256,3,3] -> packed dev */
-int sdn_conv_pack_weights(const float *w_oihw, void *packed, sdn_stream_t stream);
-/* x dev f32 [H*W,256] -> hi/lo planes */
-int sdn_conv_planes_from_f32(const float *x, void *out_hi, void *out_lo, int H, int W, sdn_stream_t stream);
-int sdn_conv3x3(const void *in_hi, const void *in_lo, const void *packed, const float *bias, const float *resid,
-                const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32, int H, int W,
-                int n_workgroups, sdn_stream_t stream);
+/* 0 for an unsupported (cin, taps) */
+size_t sdn_conv_packed_weight_bytes(int cin, int taps);
+/* w_oihw dev f32 [256,cin,k,k] (k*k = taps) -> packed dev */
+int sdn_conv_pack_weights(const float *w_oihw, int cin, int taps, void *packed, sdn_stream_t stream);
+/* x dev f32 [H*W,channels] -> hi/lo planes */
+int sdn_conv_planes_from_f32(const float *x, int channels, void *out_hi, void *out_lo, int H, int W, sdn_stream_t stream);
+/* outputs: any of (out_hi,out_lo) planes, out_f32 rows [H*W,256], out_img [3,H*W] (with proj_w [3,256], proj_b [3]) */
+int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void *packed, const float *bias,
+             const float *resid, const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32,
+             const float *proj_w, const float *proj_b, float *out_img, int H, int W, int n_workgroups, sdn_stream_t stream);
 
 /* Sky MLP for every ray + per-feature sum over rays: SKYMLP.forward(positional_encoding(raydirs, 5, incl_orig), z)
  * (imaginaire/generators/gancraft_base.py:150-169; the frame mean of scenedreamer.py:592-598 = sky_sum / n_rays).

@@ -24,7 +24,8 @@ SOURCES = {
     "rvip.hip": ["-ffp-contract=off"],  # bit-exact vs the oracle: no FMA contraction
     "posenc.hip": [],
     "gridenc.hip": [],
-    "field.hip": (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
+    # no SLP vectorisation: hipcc pairs fp32 ops into v_pk_* and pays for it with v_mov shuffles and spills in the MLP kernel
+    "field.hip": ["-fno-slp-vectorize"] + (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
     "cnn.hip": (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

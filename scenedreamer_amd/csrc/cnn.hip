@@ -1,5 +1,6 @@
-// 3x3 convolution 256 -> 256 of the render CNN on MFMA for gfx950 (RenderCNN.conv2a/2b/3a/3b,
-// imaginaire/generators/gancraft_base.py:175-225), with the same 3-term f16 split / f32 accumulate arithmetic
+// The render CNN's convolutions on MFMA for gfx950 (RenderCNN, imaginaire/generators/gancraft_base.py:175-225): the 3x3
+// 256 -> 256 ones (conv2a/2b/3a/3b) and, with TAPS = 1, the 1x1 ones (conv1 64 -> 256, conv4a/4b 256 -> 256; conv4
+// 256 -> 3 + tanh is folded into conv4b's epilogue), with the same 3-term f16 split / f32 accumulate arithmetic
 // as the field MLP (field.hip): the image must stay within 1e-3 of the fp32 reference, which plain f16 does not.
 //
 // Formulation (transposed implicit GEMM): D^T[cout][pixel] = sum_{tap, cin} W[cout][cin][tap] * X[cin][pixel + tap].
@@ -36,7 +37,7 @@ typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const char glb_char;
 
 constexpr int CH = 256;
-constexpr int KSTEPS = 9 * 16;            // 144
+constexpr int KSTEPS_3X3 = 9 * 16;        // 144 k-steps of the 3x3 256 -> 256 convolution
 constexpr int A_BYTES = 16384;            // weight fragments of one k-step (8 row blocks, hi + lo)
 constexpr int B_BYTES = 2048;             // one wave's activation fragments of one k-step (hi + lo)
 constexpr int WAVES = 8;                  // 2 waves per SIMD: one wave's LDS/DMA/barrier time is the other's MFMA time
@@ -49,13 +50,17 @@ constexpr int PATCH_W = 16, PATCH_H = 16; // pixels per workgroup: 2 x 4 wave ti
 
 struct ConvParams {
     const _Float16 *xh, *xl;   // input planes [16][Hb*Wb][16], zero border and zero outside the frame
-    const char *wpk;           // packed weights, KSTEPS * 16 KiB
+    const char *wpk;           // packed weights, ksteps * 16 KiB
+    int ksteps;                // TAPS * (input channels / 16)
     const float *bias;         // [256] or nullptr
     const float *resid;        // fp32 [H*W][256] or nullptr
     const float *mod_w;        // [256] FiLM scale (applied as w + 1) or nullptr
     const float *mod_b;        // [256]
     _Float16 *oh, *ol;         // output planes or nullptr
     float *of32;               // fp32 [H*W][256] or nullptr
+    const float *proj_w;       // [3][256] final 1x1 projection fused into the epilogue (conv4 + tanh), or nullptr
+    const float *proj_b;       // [3]
+    float *img;                // [3][H*W]
     int H, W, Hb, Wb;          // frame and padded-buffer extent (buffer pixel (y,x) -> (y+1, x+1))
     long chunk_bytes;          // Hb*Wb*32: byte stride between channel chunks of a plane
     int gx, gy, n_groups;      // workgroup patches (16 x 16 pixels)
@@ -72,28 +77,105 @@ __device__ __forceinline__ float vmax(float a, float b) {
 }
 
 // DMA of k-step `kt` of a pass into ring position `pos`
-__device__ __forceinline__ void issue_slot(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
-    // weights: this wave's 2 of the 16 1-KiB pieces (the instruction offset applies to the global AND the LDS address)
-    const char *wsrc = p.wpk + (size_t)kt * A_BYTES + wave * 2048 + lane * 16;
-    char *wdst = lds + pos * SLOT_BYTES + wave * 2048;
-    __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 1024, 0);
-    // k order is channel-chunk major: kt = 9*s + tap.  The 9 taps of one 16-channel chunk re-read the same
-    // (patch + halo) x 32 B region, which stays in L1/L2; with tap-major order every tap re-streamed the whole patch
-    // from the Infinity Cache (measured 3.2 GB fetched per launch for 0.58 GB of input).
-    const int s = kt / 9, tap = kt - 9 * s;
-    const long toff = ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * 32 + (long)s * p.chunk_bytes;
-    char *bdst = lds + pos * SLOT_BYTES + A_BYTES + wave * B_BYTES;
-    __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + toff), (lds_char *)bdst, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xl + boff + toff), (lds_char *)(bdst + 1024), 16, 0, 0);
+// one of the 4 DMA pieces a wave contributes to ring position `pos` for k-step `kt`: 0, 1 = its 2 KiB of the weight
+// fragments, 2 / 3 = its own activation fragments (hi / lo plane)
+template <int TAPS, int PIECE>
+__device__ __forceinline__ void issue_piece(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
+    if constexpr (PIECE < 2) {
+        // (the instruction offset applies to the global AND the LDS address)
+        const char *wsrc = p.wpk + (size_t)kt * A_BYTES + wave * 2048 + lane * 16;
+        char *wdst = lds + pos * SLOT_BYTES + wave * 2048;
+        if constexpr (PIECE == 0) __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 1024, 0);
+    } else {
+        // k order is channel-chunk major: kt = 9*s + tap.  The 9 taps of one 16-channel chunk re-read the same
+        // (patch + halo) x 32 B region, which stays in L1/L2; with tap-major order every tap re-streamed the whole
+        // patch from the Infinity Cache (measured 3.2 GB fetched per launch for 0.58 GB of input).
+        long toff;
+        if constexpr (TAPS == 9) {
+            const int s = kt / 9, tap = kt - 9 * s;
+            toff = ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * 32 + (long)s * p.chunk_bytes;
+        } else {
+            toff = (long)kt * p.chunk_bytes;   // 1x1: k-step = channel chunk
+        }
+        char *bdst = lds + pos * SLOT_BYTES + A_BYTES + wave * B_BYTES;
+        if constexpr (PIECE == 2) __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + toff), (lds_char *)bdst, 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xl + boff + toff), (lds_char *)(bdst + 1024), 16, 0, 0);
+    }
 }
 
-__device__ __forceinline__ void lds_unit(const char *slot, int u, int lane, half8 (&a)[4]) {
-    const char *q = slot + u * 4096 + lane * 16;
-    a[0] = *reinterpret_cast<const half8 *>(q);
-    a[1] = *reinterpret_cast<const half8 *>(q + 1024);
-    a[2] = *reinterpret_cast<const half8 *>(q + 2048);
-    a[3] = *reinterpret_cast<const half8 *>(q + 3072);
+template <int TAPS>
+__device__ __forceinline__ void issue_slot(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
+    issue_piece<TAPS, 0>(lds, p, pos, kt, wave, lane, boff);
+    issue_piece<TAPS, 1>(lds, p, pos, kt, wave, lane, boff);
+    issue_piece<TAPS, 2>(lds, p, pos, kt, wave, lane, boff);
+    issue_piece<TAPS, 3>(lds, p, pos, kt, wave, lane, boff);
+}
+
+// Fragment reads are inline asm with hand-counted s_waitcnt: behind a pending LDS-DMA the compiler's own wait
+// insertion degrades every LDS wait to lgkmcnt(0), which drains the prefetch issued just before it and exposes one
+// LDS round trip per 6 MFMAs (measured: 1.80 -> see DESIGN.md per 3x3 launch).
+__device__ __forceinline__ unsigned lds_addr(const void *p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char *)p;
+}
+
+template <int OFF>
+__device__ __forceinline__ void ds_read16(half8 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+template <int U>
+__device__ __forceinline__ void lds_unit(unsigned slot_lane, half8 (&a)[4]) {
+    ds_read16<U * 4096>(a[0], slot_lane);
+    ds_read16<U * 4096 + 1024>(a[1], slot_lane);
+    ds_read16<U * 4096 + 2048>(a[2], slot_lane);
+    ds_read16<U * 4096 + 3072>(a[3], slot_lane);
+}
+
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// One unit (2 row blocks x one k-step, 6 MFMAs).  Behind each MFMA goes ONE piece of other work, so that the
+// texture path (DMA), the LDS and the matrix pipe all stay busy: a DMA piece of the slot AHEAD k-steps on, the
+// activation fragments of the next k-step (U == 2) and the weight fragments of the unit two units on.  The fragment
+// reads are the last LDS operations of a unit: "lgkmcnt(reads of the previous unit)" at the start of a unit means
+// this unit's fragments have landed.
+template <int TAPS, int DBG, int U>
+__device__ __forceinline__ void conv_unit(char *lds, const ConvParams &p, f32x16 (&acc)[8], half8 (&a)[4][4], half8 (&bcur)[2],
+                                          half8 (&bnext)[2], unsigned slot, unsigned slot_n, unsigned b_off, int pos_issue,
+                                          int kt_issue, long boff_issue, int wave, int lane) {
+    constexpr int ib = 2 * U;
+    half8(&au)[4] = a[U];
+    half8(&nx)[4] = a[(U + 2) & 3];
+    const unsigned src = U < 2 ? slot : slot_n;            // unit U+2 of this slot, or unit U-2 of the next one
+    constexpr int OFF = ((U + 2) & 3) * 4096;
+    lds_wait<U == 3 ? 6 : 4>();
+#define SDN_GAP(K) \
+    if constexpr (K == 0 && !(DBG & 1)) issue_piece<TAPS, U>(lds, p, pos_issue, kt_issue, wave, lane, boff_issue); \
+    if constexpr (K == 0 && U == 2) { ds_read16<0>(bnext[0], slot_n + b_off); ds_read16<1024>(bnext[1], slot_n + b_off); } \
+    if constexpr (K >= 1 && K <= 4) ds_read16<OFF + (K - 1) * 1024>(nx[K - 1], src); \
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (DBG & 16) {
+        asm volatile("" ::"v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]), "v"(bcur[0]), "v"(bcur[1]));
+        SDN_GAP(0) SDN_GAP(1) SDN_GAP(2) SDN_GAP(3) SDN_GAP(4)
+    } else {
+        acc[ib] = mfma16(au[0], bcur[0], acc[ib]);
+        SDN_GAP(0)
+        acc[ib + 1] = mfma16(au[2], bcur[0], acc[ib + 1]);
+        SDN_GAP(1)
+        acc[ib] = mfma16(au[1], bcur[0], acc[ib]);
+        SDN_GAP(2)
+        acc[ib + 1] = mfma16(au[3], bcur[0], acc[ib + 1]);
+        SDN_GAP(3)
+        acc[ib] = mfma16(au[0], bcur[1], acc[ib]);
+        SDN_GAP(4)
+        acc[ib + 1] = mfma16(au[2], bcur[1], acc[ib + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SDN_GAP
 }
 
 __device__ __forceinline__ long lane_pixel_offset(const ConvParams &p, int grp, int wave, int lane, int &py, int &px) {
@@ -104,8 +186,8 @@ __device__ __forceinline__ long lane_pixel_offset(const ConvParams &p, int grp, 
     return ((long)(py + 1) * p.Wb + (px + 1)) * 32 + h * 16;   // byte offset inside chunk 0
 }
 
-template <int DBG>
-__global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
+template <int TAPS, int DBG>
+__global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[NSLOT * SLOT_BYTES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -122,81 +204,64 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
     int pos_issue = 0, pos_use = 0;
 #pragma unroll
     for (int q = 0; q < AHEAD; q++) {
-        issue_slot(lds, p, pos_issue, q, wave, lane, boff);
+        issue_slot<TAPS>(lds, p, pos_issue, q, wave, lane, boff);
         pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
     }
+    const int ksteps = p.ksteps;
 
-    // Fragment registers: two weight units (current, next) and this wave's activation fragments.  With two waves
-    // per SIMD the other wave covers LDS latency, so one unit of look-ahead is enough (registers: 128 accumulators
-    // + 32 + 16 must stay <= 256 per wave).
-    half8 a[2][4];
-    half8 bh, bl;
+    // Fragment registers: the weight fragments of 4 units (the unit in use, the next one, the one being read) and two
+    // sets of this wave's activation fragments (k-steps alternate between them: the loop is unrolled by two so that
+    // no register copies are needed).  128 accumulators + 64 + 16 stay below the 256 registers of 2 waves / SIMD.
+    half8 a[4][4];
+    half8 b[2][2];
+    const unsigned lds_lane = lds_addr(lds) + lane * 16;
+    const unsigned b_off = A_BYTES + wave * B_BYTES;
     bool primed = false;
 
     while (true) {
         f32x16 acc[8];
+#pragma unroll
+        for (int ib = 0; ib < 8; ib++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[ib][r] = 0.f;
 #pragma unroll 1
-        for (int kt = 0; kt < KSTEPS; kt++) {
-            // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free -----
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
-            if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
-            if constexpr (!(DBG & 1)) {
-                const int qn = kt + AHEAD;   // k-step to fetch, possibly of the next patch
-                if (qn < KSTEPS) issue_slot(lds, p, pos_issue, qn, wave, lane, boff);
-                else issue_slot(lds, p, pos_issue, qn - KSTEPS, wave, lane, boff_n);
+        for (int kt2 = 0; kt2 < ksteps; kt2 += 2) {
+#pragma unroll
+            for (int par = 0; par < 2; par++) {
+                const int kt = kt2 + par;
+                // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free ---
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
+                if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+                const int qn = kt + AHEAD;   // k-step to fetch during this one, possibly of the next patch
+                const int kt_issue = qn < ksteps ? qn : qn - ksteps;
+                const long boff_issue = qn < ksteps ? boff : boff_n;
+                const int pos_i = pos_issue;
                 pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
-            }
-            const char *slot = lds + pos_use * SLOT_BYTES;
-            pos_use = pos_use + 1 == NSLOT ? 0 : pos_use + 1;
-            const char *slot_n = lds + pos_use * SLOT_BYTES;
-            if (!primed) {   // very first k-step of the kernel only
-                lds_unit(slot, 0, lane, a[0]);
-                bh = *reinterpret_cast<const half8 *>(slot + A_BYTES + wave * B_BYTES + lane * 16);
-                bl = *reinterpret_cast<const half8 *>(slot + A_BYTES + wave * B_BYTES + 1024 + lane * 16);
-                primed = true;
-            }
-            half8 bh_n, bl_n;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int ib = 2 * u;
-                half8(&au)[4] = a[u & 1];
-                // next unit (of this slot, or unit 0 + activations of the next slot, complete since this barrier)
-                if (u < 3) lds_unit(slot, u + 1, lane, a[(u + 1) & 1]);
-                else {
-                    lds_unit(slot_n, 0, lane, a[0]);
-                    bh_n = *reinterpret_cast<const half8 *>(slot_n + A_BYTES + wave * B_BYTES + lane * 16);
-                    bl_n = *reinterpret_cast<const half8 *>(slot_n + A_BYTES + wave * B_BYTES + 1024 + lane * 16);
+                const unsigned slot = lds_lane + pos_use * SLOT_BYTES;
+                pos_use = pos_use + 1 == NSLOT ? 0 : pos_use + 1;
+                const unsigned slot_n = lds_lane + pos_use * SLOT_BYTES;
+                if (!primed) {   // very first k-step of the kernel only
+                    ds_read16<0>(b[0][0], slot + b_off);
+                    ds_read16<1024>(b[0][1], slot + b_off);
+                    lds_unit<0>(slot, a[0]);
+                    lds_unit<1>(slot, a[1]);
+                    primed = true;
                 }
-                if constexpr (DBG & 16) {
-                    asm volatile("" ::"v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]), "v"(bh), "v"(bl));
-                    if (kt == 0) for (int r = 0; r < 16; r++) { acc[ib][r] = 0.f; acc[ib + 1][r] = 0.f; }
-                } else {
-                if (kt == 0) {
-                    f32x16 z;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) z[r] = 0.f;
-                    acc[ib] = mfma16(au[0], bh, z);
-                    acc[ib + 1] = mfma16(au[2], bh, z);
-                } else {
-                    acc[ib] = mfma16(au[0], bh, acc[ib]);
-                    acc[ib + 1] = mfma16(au[2], bh, acc[ib + 1]);
-                }
-                acc[ib] = mfma16(au[1], bh, acc[ib]);
-                acc[ib + 1] = mfma16(au[3], bh, acc[ib + 1]);
-                acc[ib] = mfma16(au[0], bl, acc[ib]);
-                acc[ib + 1] = mfma16(au[2], bl, acc[ib + 1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                conv_unit<TAPS, DBG, 0>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
+                conv_unit<TAPS, DBG, 1>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
+                conv_unit<TAPS, DBG, 2>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
+                conv_unit<TAPS, DBG, 3>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
             }
-            bh = bh_n;
-            bl = bl_n;
         }
+        // the prefetches of the (possibly non-existent) next patch's first units must land before registers are reused
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
         // ---- epilogue of this patch -----------------------------------------------------------------------------
         const bool in_frame = py < p.H && px < p.W;
         if (in_frame) {
             const long orow = (long)py * p.W + px;                          // fp32 rows are unpadded
             const long ppix = (long)(py + 1) * p.Wb + (px + 1);             // padded pixel index
+            float pj[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int ib = 0; ib < 8; ib++) {
 #pragma unroll
@@ -219,6 +284,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
                     }
 #pragma unroll
                     for (int e = 0; e < 4; e++) v[e] = vmax(v[e], 0.2f * v[e]);   // LeakyReLU(0.2)
+                    if (p.proj_w) {   // conv4 (256 -> 3, 1x1): this lane's 4 channels of its pixel
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const float4 w = *reinterpret_cast<const float4 *>(p.proj_w + c * CH + c0);
+                            pj[c] += w.x * v[0] + w.y * v[1] + w.z * v[2] + w.w * v[3];
+                        }
+                    }
                     if (p.of32) *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0) = make_float4(v[0], v[1], v[2], v[3]);
                     if (p.oh) {
                         const fp16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
@@ -231,6 +303,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
                         *reinterpret_cast<half4 *>(p.oh + po) = hv;
                         *reinterpret_cast<half4 *>(p.ol + po) = lv;
                     }
+                }
+            }
+            if (p.proj_w) {   // the two half-waves hold the two channel halves of the same pixel
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float t = pj[c] + __shfl_xor(pj[c], 32);
+                    if (h == 0) p.img[(long)c * p.H * p.W + orow] = tanhf(t + p.proj_b[c]);   // gancraft_base.py:603
                 }
             }
         }
@@ -247,20 +326,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_kernel(const ConvParams p) {
     __builtin_amdgcn_s_barrier();
 }
 
-// ---- weight packing: W [256][256][3][3] (PyTorch OIHW) -> [k-step t = 9*s + tap][unit][frag][64 lanes][8] ------------
-__global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict__ W, half8 *__restrict__ out) {
+// ---- weight packing: W [256][cin][taps] (PyTorch OIHW) -> [k-step t = taps*s + tap][unit][frag][64 lanes][8] ----------
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict__ W, half8 *__restrict__ out, int cin, int taps) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // (t, ib, lane)
-    if (g >= (size_t)KSTEPS * 8 * 64) return;
+    if (g >= (size_t)(cin / 16) * taps * 8 * 64) return;
     const int lane = (int)(g % 64);
     const int ib = (int)((g / 64) % 8);
     const int t = (int)(g / (64 * 8));
-    const int s = t / 9, tap = t - 9 * s;   // same k order as issue_slot
+    const int s = t / taps, tap = t - taps * s;   // same k order as issue_slot
     const int co = 32 * ib + (lane & 31), h = lane >> 5;
     half8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         const int ci = 16 * s + 8 * h + e;
-        const float v = W[((size_t)co * CH + ci) * 9 + tap];
+        const float v = W[((size_t)co * cin + ci) * taps + tap];
         const _Float16 vh = (_Float16)v;
         hi[e] = vh;
         lo[e] = (_Float16)(v - (float)vh);
@@ -271,15 +350,15 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict_
     out[base + 64] = lo;
 }
 
-// ---- fp32 rows [H*W][256] -> padded f16 hi / lo planes ------------------------------------------------------------------
+// ---- fp32 rows [H*W][C] -> padded f16 hi / lo planes [C/16][Hb*Wb][16] ------------------------------------------------
 __global__ __launch_bounds__(256) void planes_kernel(const float *__restrict__ x, _Float16 *__restrict__ oh,
-                                                     _Float16 *__restrict__ ol, int H, int W, int Hb, int Wb) {
-    const long n = (long)H * W * (CH / 4);
+                                                     _Float16 *__restrict__ ol, int H, int W, int Hb, int Wb, int C) {
+    const long n = (long)H * W * (C / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const long pix = i / (CH / 4);
-        const int c0 = (int)(i % (CH / 4)) * 4;
+        const long pix = i / (C / 4);
+        const int c0 = (int)(i % (C / 4)) * 4;
         const int y = (int)(pix / W), xx = (int)(pix % W);
-        const float4 v = *reinterpret_cast<const float4 *>(x + pix * CH + c0);
+        const float4 v = *reinterpret_cast<const float4 *>(x + pix * C + c0);
         const fp16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
         const fp16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
         const fp16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
@@ -302,35 +381,44 @@ void sdn_conv_plane_dims(int H, int W, int *Hb, int *Wb) {
     *Wb = sdn::div_up(W, PATCH_W) * PATCH_W + 2;
 }
 
-size_t sdn_conv_packed_weight_bytes(void) { return (size_t)KSTEPS * A_BYTES; }
+static bool conv_shape_ok(int cin, int taps) { return (taps == 9 && cin == 256) || (taps == 1 && cin >= 64 && cin <= 256 && cin % 16 == 0); }
 
-int sdn_conv_pack_weights(const float *w_oihw, void *packed, sdn_stream_t stream) {
+size_t sdn_conv_packed_weight_bytes(int cin, int taps) { return conv_shape_ok(cin, taps) ? (size_t)(cin / 16) * taps * A_BYTES : 0; }
+
+int sdn_conv_pack_weights(const float *w_oihw, int cin, int taps, void *packed, sdn_stream_t stream) {
     SDN_REQUIRE(w_oihw && packed, "sdn_conv_pack_weights: null pointer");
-    const size_t n = (size_t)KSTEPS * 8 * 64;
+    SDN_REQUIRE(conv_shape_ok(cin, taps), "sdn_conv_pack_weights: supported shapes are 3x3 256->256 and 1x1 (64..256, multiple of 16)->256");
+    const size_t n = (size_t)(cin / 16) * taps * 8 * 64;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)sdn::div_up<size_t>(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, (half8 *)packed);
+                       w_oihw, (half8 *)packed, cin, taps);
     return sdn::check_launch("sdn_conv_pack_weights");
 }
 
-int sdn_conv_planes_from_f32(const float *x, void *out_hi, void *out_lo, int H, int W, sdn_stream_t stream) {
+int sdn_conv_planes_from_f32(const float *x, int channels, void *out_hi, void *out_lo, int H, int W, sdn_stream_t stream) {
     SDN_REQUIRE(x && out_hi && out_lo && H > 0 && W > 0, "sdn_conv_planes_from_f32: bad argument");
+    SDN_REQUIRE(channels >= 16 && channels <= 256 && channels % 16 == 0, "sdn_conv_planes_from_f32: channels must be a multiple of 16 in [16, 256]");
     int Hb, Wb;
     sdn_conv_plane_dims(H, W, &Hb, &Wb);
     hipLaunchKernelGGL(planes_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, x, (_Float16 *)out_hi, (_Float16 *)out_lo,
-                       H, W, Hb, Wb);
+                       H, W, Hb, Wb, channels);
     return sdn::check_launch("sdn_conv_planes_from_f32");
 }
 
-int sdn_conv3x3(const void *in_hi, const void *in_lo, const void *packed, const float *bias, const float *resid,
-                const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32, int H, int W,
-                int n_workgroups, sdn_stream_t stream) {
-    SDN_REQUIRE(in_hi && in_lo && packed && H > 0 && W > 0, "sdn_conv3x3: bad argument");
-    SDN_REQUIRE((out_hi && out_lo) || out_f32, "sdn_conv3x3: no output requested");
-    SDN_REQUIRE((mod_w == nullptr) == (mod_b == nullptr), "sdn_conv3x3: mod_w and mod_b go together");
+int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void *packed, const float *bias, const float *resid,
+             const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32, const float *proj_w,
+             const float *proj_b, float *out_img, int H, int W, int n_workgroups, sdn_stream_t stream) {
+    SDN_REQUIRE(in_hi && in_lo && packed && H > 0 && W > 0, "sdn_conv: bad argument");
+    SDN_REQUIRE(conv_shape_ok(cin, taps), "sdn_conv: supported shapes are 3x3 256->256 and 1x1 (64..256, multiple of 16)->256");
+    SDN_REQUIRE((out_hi && out_lo) || out_f32 || out_img, "sdn_conv: no output requested");
+    SDN_REQUIRE((mod_w == nullptr) == (mod_b == nullptr), "sdn_conv: mod_w and mod_b go together");
+    SDN_REQUIRE((proj_w == nullptr) == (out_img == nullptr) && (proj_w == nullptr) == (proj_b == nullptr),
+                "sdn_conv: proj_w, proj_b and out_img go together");
     ConvParams p;
     p.xh = (const _Float16 *)in_hi; p.xl = (const _Float16 *)in_lo; p.wpk = (const char *)packed;
+    p.ksteps = (cin / 16) * taps;
     p.bias = bias; p.resid = resid; p.mod_w = mod_w; p.mod_b = mod_b;
     p.oh = (_Float16 *)out_hi; p.ol = (_Float16 *)out_lo; p.of32 = out_f32;
+    p.proj_w = proj_w; p.proj_b = proj_b; p.img = out_img;
     p.H = H; p.W = W;
     sdn_conv_plane_dims(H, W, &p.Hb, &p.Wb);
     p.chunk_bytes = (long)p.Hb * p.Wb * 32;
@@ -339,21 +427,25 @@ int sdn_conv3x3(const void *in_hi, const void *in_lo, const void *packed, const 
     p.n_groups = p.gx * p.gy;
     int wg = n_workgroups > 0 ? n_workgroups : 256;
     if (wg > p.n_groups) wg = p.n_groups;
+    if (taps == 1) {
+        hipLaunchKernelGGL((conv_kernel<1, 0>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
+        return sdn::check_launch("sdn_conv");
+    }
     static const int dbg = [] {
         const char *e = getenv("SDN_CONV_DBG");   // timing experiments only; results are wrong unless 0
         return e ? atoi(e) : 0;
     }();
     switch (dbg) {
 #ifdef SDN_MLP_ABLATION
-        case 1: hipLaunchKernelGGL(conv3x3_kernel<1>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 2: hipLaunchKernelGGL(conv3x3_kernel<2>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 3: hipLaunchKernelGGL(conv3x3_kernel<3>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 16: hipLaunchKernelGGL(conv3x3_kernel<16>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 19: hipLaunchKernelGGL(conv3x3_kernel<19>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 1: hipLaunchKernelGGL((conv_kernel<9, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL((conv_kernel<9, 2>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 3: hipLaunchKernelGGL((conv_kernel<9, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 16: hipLaunchKernelGGL((conv_kernel<9, 16>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 19: hipLaunchKernelGGL((conv_kernel<9, 19>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
 #endif
-        default: hipLaunchKernelGGL(conv3x3_kernel<0>, dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL((conv_kernel<9, 0>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
     }
-    return sdn::check_launch("sdn_conv3x3");
+    return sdn::check_launch("sdn_conv");
 }
 
 }  // extern "C"

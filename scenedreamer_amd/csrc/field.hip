@@ -460,6 +460,7 @@ struct Ring {
     int wave;             // wave index as a scalar (readfirstlane)
     int lane;
     int voff;             // per-lane byte offset of this wave's first piece inside a slot: wave*4096 + lane*16
+    unsigned lds_lane;    // LDS byte address of this lane's 16 B inside fragment 0 of ring position 0
 };
 
 __device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_global, int slot_in_pass) {
@@ -487,14 +488,6 @@ __device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
     return pos;
 }
 
-__device__ __forceinline__ void lds_unit(const char *lds, int pos, int u_in_slot, int lane, half8 (&a)[4]) {
-    const char *q = lds + LDS_RING + pos * SLOT_BYTES + u_in_slot * 4096 + lane * 16;
-    a[0] = *reinterpret_cast<const half8 *>(q);          // (ib, hi)
-    a[1] = *reinterpret_cast<const half8 *>(q + 1024);   // (ib, lo)
-    a[2] = *reinterpret_cast<const half8 *>(q + 2048);   // (ib+1, hi)
-    a[3] = *reinterpret_cast<const half8 *>(q + 3072);   // (ib+1, lo)
-}
-
 // Per-lane view of a 256-vector in the C/D register layout: element (IB, Q, e) is feature
 // 32*IB + 16*Q + (e&3) + 8*(e>>2) + 4*h.
 // LDS reads of the small constant tables are issued through inline asm: hipcc's waitcnt pass cannot tell them
@@ -502,6 +495,34 @@ __device__ __forceinline__ void lds_unit(const char *lds, int pos, int u_in_slot
 // one, draining the whole 7-slot DMA pipeline six times per layer (seen in the ISA; ~25 % of the kernel time).
 __device__ __forceinline__ unsigned lds_addr(const void *p) {
     return (unsigned)(size_t)(const lds_char *)p;
+}
+
+// Weight-fragment reads (LDS ring -> registers) are inline asm with HAND-COUNTED waits.  Left to hipcc, every LDS
+// wait behind a pending LDS-DMA becomes lgkmcnt(0) (219 of them per pass in the ISA of the previous version):
+// each one also drains the prefetch issued a few instructions earlier and exposes a full LDS round trip.  The rule
+// that makes the counts static: within a unit the 4 fragment reads (one behind each of the first 4 MFMAs) are the
+// LAST LDS operations issued, so "lgkmcnt(4)" at the start of unit U means "everything issued before unit U-1's
+// fragment reads has landed" = unit U's fragments (issued during unit U-2), its bias blocks and all older reads.
+// tools/check_lds_hazards.py replays the compiled ISA and checks that no instruction reads a register whose
+// ds_read has not been waited for.
+template <int OFF>
+__device__ __forceinline__ void ds_read16(half8 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+
+template <int U_IN_SLOT>
+__device__ __forceinline__ void lds_unit(const Ring &r, int pos, half8 (&a)[4]) {
+    const unsigned q = r.lds_lane + pos * SLOT_BYTES;
+    ds_read16<U_IN_SLOT * 4096>(a[0], q);          // (ib, hi)
+    ds_read16<U_IN_SLOT * 4096 + 1024>(a[1], q);   // (ib, lo)
+    ds_read16<U_IN_SLOT * 4096 + 2048>(a[2], q);   // (ib+1, hi)
+    ds_read16<U_IN_SLOT * 4096 + 3072>(a[3], q);   // (ib+1, lo)
+}
+
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // 4 x 16 B at p, p+32, p+64, p+96 (bytes): the 16 accumulator-layout values of one 32-row block
@@ -560,10 +581,18 @@ __device__ __forceinline__ f32x16 bias_block(const float *bias, int h) {
 // emitted as per-value dependent chains after the unit's last MFMA, took 9.2 ms of a 19.2 ms kernel.)
 //   fragment T = 2*IB + Q of the next layer, HS = which 4 of its 8 elements:
 //   value e is accumulator register 8*Q + 4*HS + e of row block IB = feature 32*IB + 16*Q + 8*HS + e + 4*h
+// The layer bias is added HERE (one v_add per value) instead of seeding the accumulators: a seed costs 16
+// v_accvgpr_write per row block plus an LDS read that has to be waited for right in front of the block's first MFMA.
+// The 4 bias values (and, for fc_4, the 4 density-head weights) of a half fragment are fetched one unit ahead
+// (ActIn), in front of that unit's fragment prefetches, so the unit-start wait covers them.
 struct ActRegs {
     float x[4], y[4];
     fp16x2 hp[2], lp[2];
-    f32x4 w;
+};
+
+struct ActIn {
+    f32x4 b;   // bias of the 4 features
+    f32x4 w;   // density-head weights of the 4 features (SIG only)
 };
 
 // plain v_max_f32 (fmaxf / fmed3 get a canonicalising v_max in front of every operand)
@@ -585,88 +614,123 @@ __device__ __forceinline__ void put_pairs(half8 &frag, fp16x2 p0, fp16x2 p1) {
     frag = __builtin_bit_cast(half8, t);
 }
 
+// issue (no wait) the LDS reads of a half fragment's activation inputs
+template <int T, int HS, bool SIG>
+__device__ __forceinline__ void act_fetch(const float *bias, const float *wsig, int h, ActIn &in) {
+    constexpr int F = 32 * (T / 2) + 16 * (T % 2) + 8 * HS;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(in.b) : "v"(lds_addr(bias + 4 * h)), "n"(F * 4));
+    if constexpr (SIG) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(in.w) : "v"(lds_addr(wsig + 4 * h)), "n"(F * 4));
+}
+
 template <int T, int HS, bool SIG, int STAGE>
-__device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16], half8 (&bl)[16],
+__device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const ActIn &in, half8 (&bh)[16], half8 (&bl)[16],
                                           float &part, ActRegs &g) {
     constexpr int IB = T / 2, Q = T % 2;
     if constexpr (STAGE == 0) {
 #pragma unroll
         for (int e = 0; e < 4; e++) g.y[e] = acc[IB][8 * Q + 4 * HS + e];                 // 4 x v_accvgpr_read
-        if constexpr (SIG) {   // density-head weights of these 4 features (one 16-B LDS read, asm: see lds_read_block)
-            asm volatile("ds_read_b128 %0, %1" : "=v"(g.w) : "v"(lds_addr(wsig + 32 * IB + 16 * Q + 8 * HS + 4 * h)) : "memory");
-        }
     } else if constexpr (STAGE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) g.y[e] += in.b[e];
+    } else if constexpr (STAGE == 2) {
         // a' = 1.5 x + |x| = LeakyReLU_0.2(x) / 0.4 : ONE v_fma (|x| is a free source modifier); the 0.4 lives in
         // the next layer's packed weights and in the density-head weights
 #pragma unroll
         for (int e = 0; e < 4; e++) g.x[e] = __builtin_fmaf(g.y[e], 1.5f, __builtin_fabsf(g.y[e]));
-    } else if constexpr (STAGE == 2) {
+    } else if constexpr (STAGE == 3) {
         g.hp[0] = __builtin_amdgcn_cvt_pkrtz(g.x[0], g.x[1]);
         g.hp[1] = __builtin_amdgcn_cvt_pkrtz(g.x[2], g.x[3]);
-    } else if constexpr (STAGE == 3) {
+        if constexpr (SIG) part += in.w[0] * g.x[0] + in.w[1] * g.x[1] + in.w[2] * g.x[2] + in.w[3] * g.x[3];
+    } else if constexpr (STAGE == 4) {
         // remainder x - float(hi) in one v_fma_mix_f32 per value (reads the f16 half directly)
         const unsigned int p0 = __builtin_bit_cast(unsigned int, g.hp[0]), p1 = __builtin_bit_cast(unsigned int, g.hp[1]);
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[0]) : "v"(p0), "v"(g.x[0]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[1]) : "v"(p0), "v"(g.x[1]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[2]) : "v"(p1), "v"(g.x[2]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[3]) : "v"(p1), "v"(g.x[3]));
-    } else if constexpr (STAGE == 4) {
+    } else {
         g.lp[0] = __builtin_amdgcn_cvt_pkrtz(g.y[0], g.y[1]);
         g.lp[1] = __builtin_amdgcn_cvt_pkrtz(g.y[2], g.y[3]);
-        if constexpr (SIG) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g.w)::"memory");
-            part += g.w[0] * g.x[0] + g.w[1] * g.x[1] + g.w[2] * g.x[2] + g.w[3] * g.x[3];
-        }
-    } else {
         put_pairs<HS>(bh[T], g.hp[0], g.hp[1]);
         put_pairs<HS>(bl[T], g.lp[0], g.lp[1]);
     }
 }
 
-// whole half-fragment at once (used where nothing can hide it: the tail of fc_1)
+// whole half-fragment at once (used where nothing can hide it: the tail of the first layer)
 template <int T, int HS, bool SIG>
-__device__ __forceinline__ void act_half(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16], half8 (&bl)[16],
-                                         float &part) {
+__device__ __forceinline__ void act_half(const f32x16 (&acc)[8], const float *bias, const float *wsig, int h, half8 (&bh)[16],
+                                         half8 (&bl)[16], float &part) {
     ActRegs g;
-    act_stage<T, HS, SIG, 0>(acc, wsig, h, bh, bl, part, g);
-    act_stage<T, HS, SIG, 1>(acc, wsig, h, bh, bl, part, g);
-    act_stage<T, HS, SIG, 2>(acc, wsig, h, bh, bl, part, g);
-    act_stage<T, HS, SIG, 3>(acc, wsig, h, bh, bl, part, g);
-    act_stage<T, HS, SIG, 4>(acc, wsig, h, bh, bl, part, g);
-    act_stage<T, HS, SIG, 5>(acc, wsig, h, bh, bl, part, g);
+    ActIn in;
+    act_fetch<T, HS, SIG>(bias, wsig, h, in);
+    if constexpr (SIG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in.b), "+v"(in.w)::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in.b)::"memory");
+    act_stage<T, HS, SIG, 0>(acc, in, bh, bl, part, g);
+    act_stage<T, HS, SIG, 1>(acc, in, bh, bl, part, g);
+    act_stage<T, HS, SIG, 2>(acc, in, bh, bl, part, g);
+    act_stage<T, HS, SIG, 3>(acc, in, bh, bl, part, g);
+    act_stage<T, HS, SIG, 4>(acc, in, bh, bl, part, g);
+    act_stage<T, HS, SIG, 5>(acc, in, bh, bl, part, g);
 }
 
 template <int T, bool SIG>
-__device__ __forceinline__ void act_step(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16], half8 (&bl)[16],
-                                         float &part) {
-    act_half<T, 0, SIG>(acc, wsig, h, bh, bl, part);
-    act_half<T, 1, SIG>(acc, wsig, h, bh, bl, part);
+__device__ __forceinline__ void act_step(const f32x16 (&acc)[8], const float *bias, const float *wsig, int h, half8 (&bh)[16],
+                                         half8 (&bl)[16], float &part) {
+    act_half<T, 0, SIG>(acc, bias, wsig, h, bh, bl, part);
+    act_half<T, 1, SIG>(acc, bias, wsig, h, bh, bl, part);
 }
 
 // One 8-row-block layer (NS k-steps) from the LDS ring.
-//   pend:  activation of the PREVIOUS layer's lower half (row blocks 4-7 -> B fragments 8..15), one group per
-//          unit from unit 0 (HAS_PEND), hidden behind this layer's first MFMAs;
+//   pend:  activation of the PREVIOUS layer's lower half (row blocks 4-7 -> B fragments 8..15, bias_pend), one
+//          half fragment per unit from unit 0 (HAS_PEND), hidden behind this layer's first MFMAs;
 //   own:   activation of this layer's upper half into B fragments 0 .. NS/2-1 during the last NS/2 k-steps of
 //          the lower half.
-// On return acc[0..3] are consumed (except fragments t >= NS/2 when NS == 8), acc[4..7] hold the lower half.
+// On return acc[0..3] are consumed (except fragments t >= NS/2 when NS < 16), acc[4..7] hold the lower half.
 // Every index below is a compile-time constant (template recursion over the unit number): register arrays must
 // never be indexed dynamically or they end up in scratch memory.
 constexpr int RING_DEPTH = 3;   // register ring of fragment units: 2 units (384 matrix cycles) ahead of the MFMAs
 
 struct LayerState {
     half8 ring[RING_DEPTH][4];
+    ActIn in[2];                // activation inputs of unit U in in[U & 1], fetched during unit U-1
     int pos_cur, pos_nxt;
 };
 
-// one LDS read of the register ring's next unit (fragment F of unit UN)
-__device__ __forceinline__ void lds_frag(const char *lds, int pos, int u_in_slot, int lane, int f, half8 &dst) {
-    dst = *reinterpret_cast<const half8 *>(lds + LDS_RING + pos * SLOT_BYTES + u_in_slot * 4096 + f * 1024 + lane * 16);
+// one LDS read of the register ring's next unit (fragment F of unit U_IN_SLOT of ring position pos)
+template <int U_IN_SLOT, int F>
+__device__ __forceinline__ void lds_frag(const Ring &r, int pos, half8 &dst) {
+    ds_read16<U_IN_SLOT * 4096 + F * 1024>(dst, r.lds_lane + pos * SLOT_BYTES);
+}
+
+// which activation work is hidden in unit U of a layer8
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
+struct ActPlan {
+    static constexpr bool IN_RANGE = U >= 0 && U < NS * 4;
+    static constexpr int HALF = U / (2 * NS), REM = U % (2 * NS), S = REM >> 1;
+    // the previous layer's lower half (fragments 8..15, half a fragment per unit over units 0..15: fragment 8+k
+    // is first needed at unit 16+2k), or this layer's upper half (fragments 0..NS/2-1) during the last NS/2 k-steps
+    // of the lower half
+    static constexpr bool PEND = IN_RANGE && HAS_PEND && U < 16 && !(DBG & 4);
+    static constexpr bool OWN = IN_RANGE && HALF == 1 && S >= NS / 2 && !(DBG & 4);
+    static constexpr int M = U - 3 * NS;
+    static constexpr int T = PEND ? 8 + U / 2 : (OWN ? M / 2 : 0);
+    static constexpr int HS = PEND ? U % 2 : (OWN ? M % 2 : 0);
+    static constexpr bool SIG = PEND ? SIG_PEND : SIG_OWN;
+    static constexpr bool ACT = PEND || OWN;
+};
+
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
+__device__ __forceinline__ void layer8_fetch(const float *bias, const float *bias_pend, const float *wsig, int h, LayerState &st) {
+    using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U>;
+    if constexpr (P::ACT) act_fetch<P::T, P::HS, P::SIG>(P::PEND ? bias_pend : bias, wsig, h, st.in[U & 1]);
 }
 
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
 __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
-                                            f32x16 (&acc)[8], const float *bias, const float *wsig, int h, float &part) {
+                                            f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
+                                            int h, float &part) {
     constexpr int UNITS = NS * 4, RD = RING_DEPTH, UPS = 4;
+    using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U>;
     if constexpr (U % UPS == 0 && U != 0) {
         st.pos_cur = ring_acquire<DBG>(lds, r);
         st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
@@ -674,33 +738,31 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     constexpr int UN = U + RD - 1;
     constexpr bool PF = UN < UNITS && !(DBG & 8);
     const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
-    constexpr int HALF = U / (2 * NS), REM = U % (2 * NS), S = REM >> 1, IB = 4 * HALF + 2 * (REM & 1);
-    // activation work hidden in this unit: the previous layer's lower half (fragments 8..15, half a fragment per
-    // unit over units 0..15: fragment 8+k is first needed at unit 16+2k), or this layer's upper half
-    // (fragments 0..NS/2-1) during the last NS/2 k-steps of the lower half
-    constexpr bool PEND = HAS_PEND && U < 16 && !(DBG & 4);
-    constexpr bool OWN = HALF == 1 && S >= NS / 2 && !(DBG & 4);
-    constexpr int M = U - 3 * NS;
-    constexpr int T = PEND ? 8 + U / 2 : (OWN ? M / 2 : 0);
-    constexpr int HS = PEND ? U % 2 : (OWN ? M % 2 : 0);
-    constexpr bool SIG = PEND ? SIG_PEND : SIG_OWN;
-    constexpr bool ACT = PEND || OWN;
+    constexpr int S = P::S, IB = 4 * P::HALF + 2 * (P::REM & 1);
+    constexpr int T = P::T, HS = P::HS;
+    constexpr bool SIG = P::SIG, ACT = P::ACT;
     ActRegs g;
     half8(&a)[4] = st.ring[U % RD];
     half8(&nx)[4] = st.ring[UN % RD];
+    const ActIn &in = st.in[U & 1];
+    // this unit's fragments (issued during unit U-2) and activation inputs (issued at the start of unit U-1) have
+    // landed once only unit U-1's 4 fragment reads are outstanding
+    constexpr bool PF_PREV = U == 0 || ((U - 1 + RD - 1) < UNITS && !(DBG & 8));
+    lds_wait<PF_PREV ? 4 : 0>();
+    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
-    if constexpr (ACT) act_stage<T, HS, SIG, K>(acc, wsig, h, bh, bl, part, g); \
-    if constexpr (PF && K < 4) lds_frag(lds, pf_pos, UN % UPS, r.lane, (K) & 3, nx[(K) & 3]); \
+    if constexpr (ACT) act_stage<T, HS, SIG, K>(acc, in, bh, bl, part, g); \
+    if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DBG & 16) {
         asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(bh[S]), "v"(bl[S]));
-        if constexpr (S == 0) { acc[IB] = bias_block<IB>(bias, h); acc[IB + 1] = bias_block<IB + 1>(bias, h); }
+        if constexpr (S == 0) { acc[IB] = zero16(); acc[IB + 1] = zero16(); }
         SDN_STAGE(0) SDN_STAGE(1) SDN_STAGE(2) SDN_STAGE(3) SDN_STAGE(4) SDN_STAGE(5)
     } else {
-        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], bias_block<IB>(bias, h));
+        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], zero16());
         else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
         SDN_STAGE(0)
-        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], bias_block<IB + 1>(bias, h));
+        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], zero16());
         else acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
         SDN_STAGE(1)
         acc[IB] = mfma16(a[1], bh[S], acc[IB]);
@@ -718,27 +780,42 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int... Us>
 __device__ __forceinline__ void layer8_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
                                              half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8], const float *bias,
-                                             const float *wsig, int h, float &part) {
-    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, acc, bias, wsig, h, part), ...);
+                                             const float *bias_pend, const float *wsig, int h, float &part) {
+    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, acc, bias, bias_pend, wsig, h, part), ...);
 }
 
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN>
 __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
-                                       const float *bias, const float *wsig, int h, float &part) {
+                                       const float *bias, const float *bias_pend, const float *wsig, int h, float &part) {
     LayerState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
-    lds_unit(lds, st.pos_cur, 0, r.lane, st.ring[0]);
-    lds_unit(lds, st.pos_cur, 1, r.lane, st.ring[1]);
+    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, 0>(bias, bias_pend, wsig, h, st);
+    lds_unit<0>(r, st.pos_cur, st.ring[0]);
+    lds_unit<1>(r, st.pos_cur, st.ring[1]);
     layer8_units<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh, bl, acc, bias,
-                                                  wsig, h, part);
+                                                  bias_pend, wsig, h, part);
 }
 
-// Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of fc_6 is activated behind
-// its first 8 k-steps.
+// Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of the last hidden layer is
+// activated behind its first 8 k-steps (one whole fragment = two half fragments per unit).
+struct OutState {
+    half8 ring[RING_DEPTH][4];
+    ActIn in[2][2];
+    int pos_cur, pos_nxt;
+};
+
 template <int DBG, int U>
-__device__ __forceinline__ void out_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
-                                         const f32x16 (&acc)[8], f32x16 (&col)[2], const float *wsig, int h, float &part) {
+__device__ __forceinline__ void out_fetch(const float *bias_pend, int h, OutState &st) {
+    if constexpr (U < 8 && !(DBG & 4)) {
+        act_fetch<8 + U, 0, false>(bias_pend, bias_pend, h, st.in[U & 1][0]);
+        act_fetch<8 + U, 1, false>(bias_pend, bias_pend, h, st.in[U & 1][1]);
+    }
+}
+
+template <int DBG, int U>
+__device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8 (&bh)[16], half8 (&bl)[16],
+                                         const f32x16 (&acc)[8], f32x16 (&col)[2], const float *bias_pend, int h, float &part) {
     constexpr int UNITS = 16, RD = RING_DEPTH, UPS = 4;
     if constexpr (U % UPS == 0 && U != 0) {
         st.pos_cur = ring_acquire<DBG>(lds, r);
@@ -747,15 +824,19 @@ __device__ __forceinline__ void out_unit(char *lds, Ring &r, LayerState &st, hal
     constexpr int UN = U + RD - 1;
     constexpr bool PF = UN < UNITS && !(DBG & 8);
     const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
-    // fc_6's lower half -> fragments 8..15, one whole fragment per unit over units 0..7 (fragment 8+k is needed at unit 8+k)
+    // lower half -> fragments 8..15, one whole fragment per unit over units 0..7 (fragment 8+k is needed at unit 8+k)
     constexpr bool ACT = U < 8 && !(DBG & 4);
     constexpr int T = ACT ? 8 + U : 8;
     ActRegs g0, g1;
     half8(&a)[4] = st.ring[U % RD];
     half8(&nx)[4] = st.ring[UN % RD];
+    const ActIn &in0 = st.in[U & 1][0], &in1 = st.in[U & 1][1];
+    constexpr bool PF_PREV = U == 0 || ((U - 1 + RD - 1) < UNITS && !(DBG & 8));
+    lds_wait<PF_PREV ? 4 : 0>();
+    out_fetch<DBG, U + 1>(bias_pend, h, st);
 #define SDN_STAGE(K) \
-    if constexpr (ACT) { act_stage<T, 0, false, K>(acc, wsig, h, bh, bl, part, g0); act_stage<T, 1, false, K>(acc, wsig, h, bh, bl, part, g1); } \
-    if constexpr (PF && K < 4) lds_frag(lds, pf_pos, UN % UPS, r.lane, (K) & 3, nx[(K) & 3]); \
+    if constexpr (ACT) { act_stage<T, 0, false, K>(acc, in0, bh, bl, part, g0); act_stage<T, 1, false, K>(acc, in1, bh, bl, part, g1); } \
+    if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
     col[0] = mfma16(a[0], bh[U], col[0]);
     SDN_STAGE(0)
@@ -773,21 +854,22 @@ __device__ __forceinline__ void out_unit(char *lds, Ring &r, LayerState &st, hal
 }
 
 template <int DBG, int... Us>
-__device__ __forceinline__ void out_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
+__device__ __forceinline__ void out_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, OutState &st,
                                           half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8], f32x16 (&col)[2],
-                                          const float *wsig, int h, float &part) {
-    (out_unit<DBG, Us>(lds, r, st, bh, bl, acc, col, wsig, h, part), ...);
+                                          const float *bias_pend, int h, float &part) {
+    (out_unit<DBG, Us>(lds, r, st, bh, bl, acc, col, bias_pend, h, part), ...);
 }
 
 template <int DBG>
 __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8],
-                                          f32x16 (&col)[2], const float *wsig, int h, float &part) {
-    LayerState st;
+                                          f32x16 (&col)[2], const float *bias_pend, int h, float &part) {
+    OutState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
-    lds_unit(lds, st.pos_cur, 0, r.lane, st.ring[0]);
-    lds_unit(lds, st.pos_cur, 1, r.lane, st.ring[1]);
-    out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, wsig, h, part);
+    out_fetch<DBG, 0>(bias_pend, h, st);
+    lds_unit<0>(r, st.pos_cur, st.ring[0]);
+    lds_unit<1>(r, st.pos_cur, st.ring[1]);
+    out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, bias_pend, h, part);
 }
 
 template <int DBG>
@@ -808,6 +890,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     r.wave = __builtin_amdgcn_readfirstlane(wave);
     r.lane = lane;
     r.voff = r.wave * 4096 + lane * 16;
+    r.lds_lane = (unsigned)(size_t)(const lds_char *)(lds + LDS_RING) + lane * 16;
 #pragma unroll
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
     r.next_in_pass = DMA_AHEAD;
@@ -852,25 +935,27 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             const float *wsig = cst + C_WSIGMA;
             // ---- fc_1: 8 k-steps; its upper half is activated into fragments 0..3 behind its own tail, the rest of
             //      the upper half (fragments 4..7) right after it, its lower half behind fc_2's head ------------------
-            layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, cst + C_LABEL_BIAS + lab * HID, wsig, h, part);
-            act_step<4, false>(acc, wsig, h, bh, bl, part);
-            act_step<5, false>(acc, wsig, h, bh, bl, part);
-            act_step<6, false>(acc, wsig, h, bh, bl, part);
-            act_step<7, false>(acc, wsig, h, bh, bl, part);
+            const float *bias1 = cst + C_LABEL_BIAS + lab * HID;
+            layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, bias1, bias1, wsig, h, part);
+            act_step<4, false>(acc, bias1, wsig, h, bh, bl, part);
+            act_step<5, false>(acc, bias1, wsig, h, bh, bl, part);
+            act_step<6, false>(acc, bias1, wsig, h, bh, bl, part);
+            act_step<7, false>(acc, bias1, wsig, h, bh, bl, part);
             // ---- fc_2 .. fc_6.  fc_4 (l == 2) feeds the density head (layers.py:114): its upper half is activated
             //      inside l == 2, its lower half as the pending work of l == 3 ----------------------------------------
 #pragma unroll 1
             for (int l = 0; l < 5; l++) {
                 const float *bias = cst + C_BETA + l * HID;
-                if (l == 2) layer8<DBG, 16, true, false, true>(lds, r, bh, bl, acc, bias, wsig, h, part);
-                else if (l == 3) layer8<DBG, 16, true, true, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
-                else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
+                const float *bias_pend = l == 0 ? bias1 : bias - HID;   // the previous layer's (its lower half is pending)
+                if (l == 2) layer8<DBG, 16, true, false, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                else if (l == 3) layer8<DBG, 16, true, true, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
             }
             // ---- fc_out_c ------------------------------------------------------------------------------------------
             f32x16 col[2];
             col[0] = bias_block<0>(cst + C_BC, h);
             col[1] = bias_block<1>(cst + C_BC, h);
-            layer_out<DBG>(lds, r, bh, bl, acc, col, wsig, h, part);
+            layer_out<DBG>(lds, r, bh, bl, acc, col, cst + C_BETA + 4 * HID, h, part);
             const float sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
             // ---- volume rendering (mc_utils.py:154-161) over the 4 samples of each ray in this pass ---------------
             const float fe = fmaxf(sigma, 0.f) * dist;
@@ -1021,6 +1106,7 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
     r.wave = __builtin_amdgcn_readfirstlane(wave);
     r.lane = lane;
     r.voff = r.wave * 4096 + lane * 16;
+    r.lds_lane = (unsigned)(size_t)(const lds_char *)(lds + LDS_RING) + lane * 16;
 #pragma unroll
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
     r.next_in_pass = DMA_AHEAD;
@@ -1047,19 +1133,21 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
         const float *nul = cst;
         // fc1 (+ style term): 4 k-steps; fragments 0,1 of its upper half are activated behind its own tail, the
         // remaining six (2..7) right after, the lower half behind fc2's head
-        layer8<DBG, 4, false, false, false>(lds, r, bh, bl, acc, cst + SC_BIAS1, nul, h, part);
-        act_step<2, false>(acc, nul, h, bh, bl, part);
-        act_step<3, false>(acc, nul, h, bh, bl, part);
-        act_step<4, false>(acc, nul, h, bh, bl, part);
-        act_step<5, false>(acc, nul, h, bh, bl, part);
-        act_step<6, false>(acc, nul, h, bh, bl, part);
-        act_step<7, false>(acc, nul, h, bh, bl, part);
+        layer8<DBG, 4, false, false, false>(lds, r, bh, bl, acc, cst + SC_BIAS1, cst + SC_BIAS1, nul, h, part);
+        act_step<2, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<3, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<4, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<5, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<6, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<7, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
 #pragma unroll 1
-        for (int l = 0; l < 4; l++) layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, cst + SC_BIASH + l * HID, nul, h, part);
+        for (int l = 0; l < 4; l++)
+            layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, cst + SC_BIASH + l * HID,
+                                                l == 0 ? cst + SC_BIAS1 : cst + SC_BIASH + (l - 1) * HID, nul, h, part);
         f32x16 col[2];
         col[0] = bias_block<0>(cst + SC_BC, h);
         col[1] = bias_block<1>(cst + SC_BC, h);
-        layer_out<DBG>(lds, r, bh, bl, acc, col, nul, h, part);
+        layer_out<DBG>(lds, r, bh, bl, acc, col, cst + SC_BIASH + 3 * HID, h, part);
         // ---- store sky_c[ray][feature] and accumulate the per-feature sum over rays -----------------------------
         if (ray_ok) {
 #pragma unroll
@@ -1258,6 +1346,8 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     switch (dbg) {
 #ifdef SDN_MLP_ABLATION
         case 1: hipLaunchKernelGGL(mlp_kernel<1>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring DMA
+        case 2: hipLaunchKernelGGL(mlp_kernel<2>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring barrier
+        case 3: hipLaunchKernelGGL(mlp_kernel<3>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
         case 4: hipLaunchKernelGGL(mlp_kernel<4>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no activation VALU
         case 8: hipLaunchKernelGGL(mlp_kernel<8>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no fragment ds_read
         case 16: hipLaunchKernelGGL(mlp_kernel<16>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // no MFMA

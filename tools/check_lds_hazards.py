@@ -1,0 +1,99 @@
+#!/usr/bin/env python
+"""Static check of the hand-counted LDS waits in the MFMA kernels (field.hip, cnn.hip).
+
+The weight-fragment / bias reads are inline-asm ds_read_b128 whose completion hipcc does not track, so nothing but the
+hand-written `s_waitcnt lgkmcnt(N)` keeps an instruction from reading a register whose data has not landed.  This
+script compiles the kernels to ISA and replays every kernel linearly: each ds_read* pushes its destination registers
+on an in-order queue, `s_waitcnt lgkmcnt(N)` retires all but the newest N entries (LDS returns in order; SMEM loads
+are treated as queue entries too, conservatively), and any instruction that reads OR overwrites a register still in
+the queue is reported.  Branch targets are handled conservatively: the queue is carried across labels as is (the
+kernels' loops are straight-line bodies).
+
+    python tools/check_lds_hazards.py            # exit status 1 if a hazard is found
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = {"field.hip": ["-fno-slp-vectorize"], "cnn.hip": []}
+KERNELS = ("mlp_kernelILi0", "sky_kernelILi0", "conv_kernelILi9ELi0", "conv_kernelILi1ELi0")
+REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1):
+            out.update((m.group(1), i) for i in range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add((m.group(4), int(m.group(5))))
+    return out
+
+
+def check_kernel(name, lines):
+    queue, problems, n_reads = [], [], 0
+    for ln, raw in lines:
+        line = raw.split(";")[0].strip()
+        if not line or line.endswith(":") or line.startswith("."):
+            continue
+        op, _, rest = line.partition(" ")
+        if op == "s_waitcnt":
+            m = re.search(r"lgkmcnt\((\d+)\)", rest)
+            if m:
+                keep = int(m.group(1))
+                queue = queue[len(queue) - keep:] if keep else []
+            continue
+        pending = set().union(*[q[0] for q in queue]) if queue else set()
+        if op.startswith("ds_read") or op.startswith("ds_load"):
+            dst, _, srcs = rest.partition(",")
+            used = regs_of(srcs)
+            if used & pending:
+                problems.append((ln, raw.strip(), "address register pending"))
+            d = regs_of(dst)
+            if d & pending:
+                problems.append((ln, raw.strip(), "overwrites a pending destination"))
+            queue.append((d, ln))
+            n_reads += 1
+            continue
+        if op.startswith("s_load") or op.startswith("s_buffer_load"):
+            queue.append((set(), ln))   # counts on lgkmcnt, scalar destination
+            continue
+        if op.startswith("ds_"):        # ds_write / ds_bpermute ...: count, no vector destination tracked here
+            if regs_of(rest) & pending:
+                problems.append((ln, raw.strip(), "reads a pending register"))
+            queue.append((regs_of(rest.split(",")[0]) if "permute" in op or "swizzle" in op else set(), ln))
+            continue
+        if regs_of(rest) & pending:
+            problems.append((ln, raw.strip(), "touches a pending register"))
+    return n_reads, problems
+
+
+def main():
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for src, flags in SRC.items():
+            out = os.path.join(tmp, src + ".s")
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", *flags, f"-I{ROOT}/include",
+                                   f"-I{ROOT}/scenedreamer_amd/csrc", "-S", "--cuda-device-only", "-o", out,
+                                   os.path.join(ROOT, "scenedreamer_amd", "csrc", src)], stderr=subprocess.DEVNULL)
+            text = open(out).read().split("\n")
+            for k in KERNELS:
+                start = next((i for i, l in enumerate(text) if l.startswith("_Z") and k in l and l.rstrip().endswith(":") or
+                              (l.startswith("_Z") and k in l and ": " in l)), None)
+                if start is None:
+                    continue
+                end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
+                n, problems = check_kernel(k, list(enumerate(text[start:end], start + 1)))
+                print(f"{src}:{k}: {n} LDS reads replayed, {len(problems)} hazard(s)")
+                for ln, raw, why in problems[:10]:
+                    print(f"    line {ln}: {why}: {raw}")
+                bad += len(problems)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
