@@ -54,12 +54,20 @@ const char *sdn_last_error(void);
  *   out_voxel_id  dev int32 [H, W, max_samples, 1]
  *   out_depth     dev f32   [2, H, W, max_samples, 1]   (entry t, exit t2; NaN on miss)
  *   out_raydirs   dev f32   [H, W, 1, 3]
+ *   occupancy  dev u8 block-occupancy grid of THIS volume from sdn_rvip_build_occupancy, or NULL.  With it, rays
+ *              cross empty 8x16x16-cell blocks in one step; the outputs are the same bits either way.
  * Results are bit-identical to the reference source evaluated without FMA
  * contraction (see oracle/sdn_oracle.c).
  */
 int sdn_rvip(const int32_t *vox, const int64_t *dims, const int64_t *strides, const float *cam_ori,
              const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c, const int *img_dims,
-             int max_samples, int32_t *out_voxel_id, float *out_depth, float *out_raydirs, sdn_stream_t stream);
+             int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id, float *out_depth, float *out_raydirs,
+             sdn_stream_t stream);
+/* acceleration structure for sdn_rvip (no reference counterpart; rebuild whenever the volume changes):
+ * bytes needed for a volume of extent dims (0 for bad dims), and the build (one pass over the volume). */
+size_t sdn_rvip_occupancy_bytes(const int64_t *dims);
+int sdn_rvip_build_occupancy(const int32_t *vox, const int64_t *dims, const int64_t *strides, uint8_t *occupancy,
+                             sdn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * voxlib.positional_encoding / positional_encoding_backward

@@ -29,7 +29,9 @@ c_i64 = ctypes.c_int64
 _SIGNATURES = {
     "sdn_abi_version": (c_i, []),
     "sdn_last_error": (ctypes.c_char_p, []),
-    "sdn_rvip": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "sdn_rvip": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sdn_rvip_occupancy_bytes": (ctypes.c_size_t, [c_p]),
+    "sdn_rvip_build_occupancy": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_posenc_fwd": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p]),
     "sdn_posenc_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_p]),
     "sdn_grid_encode_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_u, c_u, c_u, c_u, c_f, c_u, c_i, c_p, c_u, c_i, c_p]),

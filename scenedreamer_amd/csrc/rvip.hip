@@ -9,6 +9,15 @@
 // compiled with fp contraction off and uses IEEE division / sqrt (hipcc's
 // default -fhip-fp32-correctly-rounded-divide-sqrt).
 //
+// Empty-space skipping (optional, exact): with an occupancy grid of 8 x 16 x 16-cell blocks
+// (sdn_rvip_build_occupancy) a ray whose current cell lies in an empty block jumps to the state the cell-by-cell
+// walk has when it LEAVES that block.  The walk's state is a pure function of the cell indices (every crossing time
+// is the closed form ((float)(cell + a) - o) / d), and the walk executes the three axes' crossings merged by
+// (time, axis) with the reference's <= tie-breaks; so the exit event is the smallest (time, axis) among the three
+// block-exit crossings and the other two axes have advanced through exactly the crossings that precede it in that
+// order -- found with the same float expressions the walk evaluates, hence bit-identical outputs (tests compare
+// against the oracle and against the kernel without the grid).
+//
 // MI355X mapping: one wavefront (64 lanes) owns an 8x8 pixel tile so that the
 // lanes' rays stay spatially coherent while they march (neighbouring rays read
 // neighbouring cache lines of the volume).  Four tiles (4 waves) share a
@@ -31,7 +40,46 @@ struct RvipParams {
     float c[2];
     float f;
     int32_t tiles_x, tiles_y, n_tiles;
+    const uint8_t *occ;   // [nb0][nb1][nb2] 1 = block holds a non-empty cell; nullptr = no skipping
+    int32_t nb1, nb2;
 };
+
+constexpr int BS0 = 3, BS1 = 4, BS2 = 4;   // log2 of the occupancy block extent per axis (axis 0 is the short, vertical one)
+
+// crossings of one axis that the cell-by-cell walk executes before the exit event (time T; `incl`: this axis wins
+// ties against the exit axis): returns the cell index reached.  lo / hi: the block's cell range [lo, hi) clipped to
+// the volume.
+__device__ __forceinline__ int advance_axis(int i, int lo, int hi, float o, float d, float T, bool incl) {
+    if (d > 0) {
+        // crossing into cell n happens at ((float)n - o) / d  (the walk's t for cell n-1)
+        int n = (int)floorf(o + d * T);
+        n = n < i ? i : (n > hi - 1 ? hi - 1 : n);
+        while (n + 1 <= hi - 1) {
+            const float t = ((float)(n + 1) - o) / d;
+            if (incl ? t <= T : t < T) n++; else break;
+        }
+        while (n > i) {
+            const float t = ((float)n - o) / d;
+            if (incl ? t <= T : t < T) break; else n--;
+        }
+        return n;
+    }
+    if (d < 0) {
+        // crossing into cell n (from n+1) happens at ((float)(n+1) - o) / d  (the walk's t for cell n+1)
+        int n = (int)floorf(o + d * T);
+        n = n > i ? i : (n < lo ? lo : n);
+        while (n - 1 >= lo) {
+            const float t = ((float)n - o) / d;
+            if (incl ? t <= T : t < T) n--; else break;
+        }
+        while (n < i) {
+            const float t = ((float)(n + 1) - o) / d;
+            if (incl ? t <= T : t < T) break; else n++;
+        }
+        return n;
+    }
+    return i;
+}
 
 constexpr int TILE = 8;
 constexpr int WAVES_PER_WG = 4;
@@ -107,8 +155,45 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
         int32_t blk = 0;
         while (!quit) {
             float tnow;
+            bool skipped = false;
+            if (p.occ && (unsigned)i0 < (unsigned)p.vd[0] && (unsigned)i1 < (unsigned)p.vd[1] &&
+                (unsigned)i2 < (unsigned)p.vd[2] &&
+                p.occ[((int64_t)(i0 >> BS0) * p.nb1 + (i1 >> BS1)) * p.nb2 + (i2 >> BS2)] == 0) {
+                // ---- leave the empty block in one go --------------------------------------------------------
+                const int lo0 = (i0 >> BS0) << BS0, lo1 = (i1 >> BS1) << BS1, lo2 = (i2 >> BS2) << BS2;
+                const int hi0 = min(lo0 + (1 << BS0), p.vd[0]), hi1 = min(lo1 + (1 << BS1), p.vd[1]),
+                          hi2 = min(lo2 + (1 << BS2), p.vd[2]);
+                // time of each axis' block-exit crossing: the walk's own t when it stands in the last cell
+                const float T0 = d0 > 0 ? ((float)hi0 - o0) / d0 : (d0 < 0 ? ((float)lo0 - o0) / d0 : HUGE_VALF);
+                const float T1 = d1 > 0 ? ((float)hi1 - o1) / d1 : (d1 < 0 ? ((float)lo1 - o1) / d1 : HUGE_VALF);
+                const float T2 = d2 > 0 ? ((float)hi2 - o2) / d2 : (d2 < 0 ? ((float)lo2 - o2) / d2 : HUGE_VALF);
+                if (T0 <= T1 && T0 <= T2) {
+                    tnow = T0;
+                    i0 = d0 > 0 ? hi0 : lo0 - 1;
+                    quit = d0 > 0 ? (i0 >= p.vd[0]) : (i0 < 0);
+                    i1 = advance_axis(i1, lo1, hi1, o1, d1, T0, false);
+                    i2 = advance_axis(i2, lo2, hi2, o2, d2, T0, false);
+                } else if (T1 <= T2) {
+                    tnow = T1;
+                    i1 = d1 > 0 ? hi1 : lo1 - 1;
+                    quit = d1 > 0 ? (i1 >= p.vd[1]) : (i1 < 0);
+                    i0 = advance_axis(i0, lo0, hi0, o0, d0, T1, true);
+                    i2 = advance_axis(i2, lo2, hi2, o2, d2, T1, false);
+                } else {
+                    tnow = T2;
+                    i2 = d2 > 0 ? hi2 : lo2 - 1;
+                    quit = d2 > 0 ? (i2 >= p.vd[2]) : (i2 < 0);
+                    i0 = advance_axis(i0, lo0, hi0, o0, d0, T2, true);
+                    i1 = advance_axis(i1, lo1, hi1, o1, d1, T2, true);
+                }
+                if (d0 != 0) t0 = ((float)(i0 + a0) - o0) / d0;
+                if (d1 != 0) t1 = ((float)(i1 + a1) - o1) / d1;
+                if (d2 != 0) t2 = ((float)(i2 + a2) - o2) / d2;
+                skipped = true;
+            }
             // axis choice with the reference's <= tie-breaks (:143, :160, :175)
-            if (t0 <= t1 && t0 <= t2) {
+            if (skipped) {
+            } else if (t0 <= t1 && t0 <= t2) {
                 tnow = t0;
                 i0 += s0;
                 quit = d0 > 0 ? (i0 >= p.vd[0]) : (i0 < 0);
@@ -140,12 +225,48 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
     }
 }
 
+// one workgroup per occupancy block: does any cell of the block (clipped to the volume) hold a non-zero id?
+__global__ __launch_bounds__(256) void occupancy_kernel(uint8_t *__restrict__ occ, const int32_t *__restrict__ vox, int vd0, int vd1,
+                                                        int vd2, int64_t vs0, int64_t vs1, int64_t vs2, int nb1, int nb2) {
+    const int b = blockIdx.x;
+    const int b2 = b % nb2, b1 = (b / nb2) % nb1, b0 = b / (nb2 * nb1);
+    int any = 0;
+    for (int c = threadIdx.x; c < (1 << (BS0 + BS1 + BS2)); c += 256) {
+        const int x2 = (b2 << BS2) + (c & ((1 << BS2) - 1));
+        const int x1 = (b1 << BS1) + ((c >> BS2) & ((1 << BS1) - 1));
+        const int x0 = (b0 << BS0) + (c >> (BS1 + BS2));
+        if (x0 < vd0 && x1 < vd1 && x2 < vd2) any |= vox[x0 * vs0 + x1 * vs1 + x2 * vs2] != 0;
+    }
+    any = __syncthreads_or(any);
+    if (threadIdx.x == 0) occ[b] = any ? 1 : 0;
+}
+
 }  // namespace
+
+extern "C" size_t sdn_rvip_occupancy_bytes(const int64_t *dims) {
+    if (!dims || dims[0] <= 0 || dims[1] <= 0 || dims[2] <= 0) return 0;
+    return (size_t)sdn::div_up<int64_t>(dims[0], 1 << BS0) * sdn::div_up<int64_t>(dims[1], 1 << BS1) *
+           sdn::div_up<int64_t>(dims[2], 1 << BS2);
+}
+
+extern "C" int sdn_rvip_build_occupancy(const int32_t *vox, const int64_t *dims, const int64_t *strides, uint8_t *occ,
+                                        sdn_stream_t stream) {
+    SDN_REQUIRE(vox && dims && strides && occ, "sdn_rvip_build_occupancy: null argument");
+    SDN_REQUIRE(dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dims[0] < (1ll << 31) && dims[1] < (1ll << 31) &&
+                    dims[2] < (1ll << 31),
+                "sdn_rvip_build_occupancy: bad voxel dims");
+    const size_t n = sdn_rvip_occupancy_bytes(dims);
+    SDN_REQUIRE(n < (1ull << 31), "sdn_rvip_build_occupancy: volume too large");
+    hipLaunchKernelGGL(occupancy_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, occ, vox, (int)dims[0], (int)dims[1],
+                       (int)dims[2], strides[0], strides[1], strides[2], (int)sdn::div_up<int64_t>(dims[1], 1 << BS1),
+                       (int)sdn::div_up<int64_t>(dims[2], 1 << BS2));
+    return sdn::check_launch("sdn_rvip_build_occupancy");
+}
 
 extern "C" int sdn_rvip(const int32_t *vox, const int64_t *dims, const int64_t *strides, const float *cam_ori,
                         const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
-                        const int *img_dims, int max_samples, int32_t *out_voxel_id, float *out_depth,
-                        float *out_raydirs, sdn_stream_t stream) {
+                        const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id,
+                        float *out_depth, float *out_raydirs, sdn_stream_t stream) {
     SDN_REQUIRE(vox && dims && strides && cam_ori && cam_dir && cam_up && cam_c && img_dims,
                 "sdn_rvip: null argument");
     SDN_REQUIRE(out_voxel_id && out_depth && out_raydirs, "sdn_rvip: null output");
@@ -186,6 +307,9 @@ extern "C" int sdn_rvip(const int32_t *vox, const int64_t *dims, const int64_t *
     p.tiles_x = sdn::div_up(p.W, TILE);
     p.tiles_y = sdn::div_up(p.H, TILE);
     p.n_tiles = p.tiles_x * p.tiles_y;
+    p.occ = occupancy;
+    p.nb1 = (int32_t)sdn::div_up<int64_t>(dims[1], 1 << BS1);
+    p.nb2 = (int32_t)sdn::div_up<int64_t>(dims[2], 1 << BS2);
 
     const int n_wg = sdn::div_up(p.n_tiles, WAVES_PER_WG);
     hipLaunchKernelGGL(rvip_kernel, dim3(n_wg), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, out_voxel_id,

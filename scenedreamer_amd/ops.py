@@ -38,10 +38,30 @@ def _stream(t):
     return capi.current_stream(t.device)
 
 
-def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples):
+def voxel_occupancy(in_voxel):
+    """Empty-space acceleration grid of `in_voxel` for sdn_rvip (1 byte per 8x16x16 cells, one pass over the volume).
+    It is cached ON the tensor object (an address-keyed cache would go stale when the allocator reuses the address)
+    and rebuilt after in-place edits (tensor._version)."""
+    tag = (in_voxel._version, in_voxel.data_ptr(), tuple(in_voxel.shape), tuple(in_voxel.stride()))
+    cached = getattr(in_voxel, "_sdn_occupancy", None)
+    if cached is not None and cached[0] == tag:
+        return cached[1]
+    lib = capi.lib()
+    dims, strides = _l3(*in_voxel.shape), _l3(*in_voxel.stride())
+    with torch.cuda.device(in_voxel.device):
+        occ = torch.empty(lib.sdn_rvip_occupancy_bytes(dims), dtype=torch.uint8, device=in_voxel.device)
+        capi.check(lib.sdn_rvip_build_occupancy(in_voxel.data_ptr(), dims, strides, occ.data_ptr(), _stream(in_voxel)),
+                   "sdn_rvip_build_occupancy")
+    in_voxel._sdn_occupancy = (tag, occ)
+    return occ
+
+
+def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples,
+                                       accelerate=True):
     """voxlib.ray_voxel_intersection_perspective (ray_voxel_intersection.cu:253-325).
 
     Returns [voxel_id i32[H,W,M,1], depth2 f32[2,H,W,M,1], raydirs f32[H,W,1,3]] on in_voxel's device.
+    `accelerate` (not in the reference signature) only selects exact empty-space skipping; results are identical.
     """
     _require(isinstance(in_voxel, torch.Tensor) and in_voxel.is_cuda, "in_voxel must be a CUDA tensor")
     _require(in_voxel.dtype == torch.int32, "in_voxel must be int32")
@@ -56,10 +76,11 @@ def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f
         raydirs = torch.empty((H, W, 1, 3), dtype=torch.float32, device=dev)
         if H * W * M == 0:
             return [voxel_id, depth2, raydirs]
+        occ = voxel_occupancy(in_voxel) if accelerate and in_voxel.numel() > 0 else None
         rc = capi.lib().sdn_rvip(
             in_voxel.data_ptr(), _l3(*in_voxel.shape), _l3(*in_voxel.stride()),
             _host3(cam_ori, "cam_ori"), _host3(cam_dir, "cam_dir"), _host3(cam_up, "cam_up"),
-            cam_f, _f2(float(cam_c[0]), float(cam_c[1])), _i2(H, W), M,
+            cam_f, _f2(float(cam_c[0]), float(cam_c[1])), _i2(H, W), M, occ.data_ptr() if occ is not None else None,
             voxel_id.data_ptr(), depth2.data_ptr(), raydirs.data_ptr(), _stream(in_voxel))
     capi.check(rc, "sdn_rvip")
     return [voxel_id, depth2, raydirs]

@@ -49,6 +49,21 @@ def test_rvip_invariants_at_full_size(big, hw):
         assert int(hit.sum()) > 0.3 * n
 
 
+def test_rvip_skipping_is_exact_at_full_size(big):
+    """Empty-space skipping vs the plain cell-by-cell kernel on the 2048^2 scene, whole padded frames: same bits."""
+    from scenedreamer_amd import ops
+    from scenedreamer_amd.camera import frame_intrinsics
+    R, scene, poses = big
+    for pi in range(0, 40, 3):
+        ori, d, up, cf = poses[pi]
+        f, c, cam_res = frame_intrinsics(cf, (540, 960), R.pad)
+        a = ops.ray_voxel_intersection_perspective(scene.voxel_t, ori, d, up, f, c, cam_res, R.M, accelerate=True)
+        b = ops.ray_voxel_intersection_perspective(scene.voxel_t, ori, d, up, f, c, cam_res, R.M, accelerate=False)
+        assert torch.equal(a[0], b[0]), f"pose {pi}: voxel ids differ"
+        assert torch.equal(a[1].view(torch.int32), b[1].view(torch.int32)), f"pose {pi}: depths differ"
+        assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
+
+
 @pytest.mark.parametrize("hw,ns,pi", [((540, 960), 24, 4), ((1080, 1920), 40, 12)])
 def test_fused_and_unfused_frames_agree_at_full_size(big, hw, ns, pi):
     R, scene, poses = big

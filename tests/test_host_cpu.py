@@ -131,7 +131,7 @@ def test_argument_validation_without_a_gpu():
     assert rc == -2 and b"C must be 1, 2, 4, or 8" in lib.sdn_last_error()
     rc = lib.sdn_grid_encode_fwd(p, p, 0, p, p, 8, 6, 2, 1, 0.0, 4, 0, p, 0, 0, None)
     assert rc == -2 and b"D must be" in lib.sdn_last_error()
-    rc = lib.sdn_rvip(None, p, p, p, p, p, 1.0, p, p, 2, p, p, p, None)
+    rc = lib.sdn_rvip(None, p, p, p, p, p, 1.0, p, p, 2, None, p, p, p, None)
     assert rc == -1
     assert lib.sdn_posenc_fwd(None, None, 0, 5, 3, 1, None) == 0           # empty input is a no-op
     offs = (ctypes.c_int32 * 17)(*[100 * i for i in range(17)])

@@ -25,15 +25,16 @@ def _rvip_both(ops, O, vox_np, pose, f, c, dims, M, vox_dev=None):
     ori, d, up = [np.asarray(x, np.float32) for x in pose]
     if vox_dev is None:
         vox_dev = torch.from_numpy(vox_np).cuda()
-    vid, d2, rd = ops.ray_voxel_intersection_perspective(vox_dev, torch.from_numpy(ori), torch.from_numpy(d),
-                                                         torch.from_numpy(up), f, c, dims, M)
-    torch.cuda.synchronize()
     rid, rd2, rrd = O.rvip(vox_np, ori, d, up, f, c, dims, M)
-    assert vid.shape == (dims[0], dims[1], M, 1) and d2.shape == (2, dims[0], dims[1], M, 1)
-    assert rd.shape == (dims[0], dims[1], 1, 3)
-    np.testing.assert_array_equal(vid.cpu().numpy(), rid)
-    np.testing.assert_array_equal(bits(d2.cpu().numpy()), bits(rd2))
-    np.testing.assert_array_equal(bits(rd.cpu().numpy()), bits(rrd))
+    for accelerate in (True, False):   # exact empty-space skipping on / off: the same bits
+        vid, d2, rd = ops.ray_voxel_intersection_perspective(vox_dev, torch.from_numpy(ori), torch.from_numpy(d),
+                                                             torch.from_numpy(up), f, c, dims, M, accelerate=accelerate)
+        torch.cuda.synchronize()
+        assert vid.shape == (dims[0], dims[1], M, 1) and d2.shape == (2, dims[0], dims[1], M, 1)
+        assert rd.shape == (dims[0], dims[1], 1, 3)
+        np.testing.assert_array_equal(vid.cpu().numpy(), rid)
+        np.testing.assert_array_equal(bits(d2.cpu().numpy()), bits(rd2))
+        np.testing.assert_array_equal(bits(rd.cpu().numpy()), bits(rrd))
     return rid
 
 
@@ -68,6 +69,46 @@ def test_rvip_edge_cases(ops, oracle):
     for ori, d, M in cases:
         for up_ in (up, [0.0, 1.0, 0.0]):
             _rvip_both(ops, oracle, vox, (ori, d, up_), 20.0, [7.5, 9.5], [16, 20], M)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_rvip_sparse_volume_block_skipping(ops, oracle, seed):
+    """Mostly empty volumes (floating cells, thin sheets, extents that are not multiples of the 8x16x16 occupancy
+    block) from random poses inside, on the boundary of and outside the volume: long empty-block jumps must land
+    in exactly the state of the cell-by-cell walk."""
+    rng = np.random.default_rng(seed)
+    dims = [(37, 150, 131), (64, 96, 200), (9, 257, 63)][seed - 1]
+    vox = np.zeros(dims, np.int32)
+    n = 60
+    vox[rng.integers(0, dims[0], n), rng.integers(0, dims[1], n), rng.integers(0, dims[2], n)] = rng.integers(1, 50, n)
+    vox[dims[0] // 2, :, dims[2] // 3] = 7                       # a line
+    vox[0, 10:dims[1] - 10, 5:dims[2] - 5] = 3                   # a floor sheet
+    vox_dev = torch.from_numpy(vox).cuda()
+    nhit = 0
+    for k in range(12):
+        if k % 3 == 0:      # outside, looking at the centre
+            ori = np.array([dims[0] * 1.5, -20.0 - k, dims[2] * 0.5 + k], np.float32)
+        elif k % 3 == 1:    # inside
+            ori = (rng.random(3) * np.array(dims)).astype(np.float32)
+        else:               # exactly on integer planes / the boundary
+            ori = np.array([float(dims[0]), float(rng.integers(0, dims[1])), float(rng.integers(0, dims[2]))], np.float32)
+        d = (np.array(dims, np.float32) * rng.random(3).astype(np.float32) - ori)
+        if k == 7:
+            d = np.array([0.0, 1.0, 0.0], np.float32)             # exact zeros in the direction
+        rid = _rvip_both(ops, oracle, vox, (ori, d, [1.0, 0.0, 0.0]), 35.0, [23.5, 31.5], [48, 64], 5, vox_dev)
+        nhit += int((rid != 0).sum())
+    assert nhit > 0
+
+
+def test_rvip_occupancy_follows_volume_edits(ops, oracle):
+    vox = np.zeros((16, 64, 64), np.int32)
+    vox[3, 20:40, 20:40] = 5
+    dev = torch.from_numpy(vox).cuda()
+    pose = ([14.5, 5.5, 5.5], [-0.4, 0.7, 0.6], [1.0, 0.0, 0.0])
+    _rvip_both(ops, oracle, vox, pose, 30.0, [15.5, 15.5], [32, 32], 3, dev)
+    vox[9, 8:12, 8:12] = 11                                       # in-place edit: the cached grid must be rebuilt
+    dev[9, 8:12, 8:12] = 11
+    _rvip_both(ops, oracle, vox, pose, 30.0, [15.5, 15.5], [32, 32], 3, dev)
 
 
 def test_rvip_strided_volume(ops, oracle):
