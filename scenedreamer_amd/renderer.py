@@ -236,20 +236,29 @@ class Renderer:
             sky_avg = sky_c.mean(dim=0, keepdim=True)
             B, ms_enc, per_sample, kernel = fused.time_encode_kernel(self, vid, d2, rd, cam_ori, num_samples)
             _, ms_mlp, hit = fused.time_mlp_kernel(self, vid, d2, rd, cam_ori, sky_c, sky_avg, num_samples)
-        ach_g = B * per_sample / (ms_enc * 1e-3) / 1e9
+        traffic = _profiled_traffic()
+        # encode_kernel: its compulsory HBM traffic is the feature write (512 B) + dist/label (5 B) + the ray records
+        # (84 B / ray); the 8-corner gather (4 096 B/sample of the collapsed table, 16 384 B in the reference) is served
+        # by L2 / Infinity Cache.  `achieved` prices the kernel against what it must move through HBM; the
+        # reference-equivalent gather rate (16 404 B/sample) is reported beside it.
+        hbm_per_sample = 512 + 5 + 84.0 / num_samples
+        ach_g = B * hbm_per_sample / (ms_enc * 1e-3) / 1e9
         grid = {"bound": "hbm", "kernel": kernel, "achieved": ach_g, "peak": hbm_peak_gbps, "unit": "GB/s",
-                "frac": ach_g / hbm_peak_gbps, "traffic": None, "samples_per_launch": B,
-                "algorithmic_bytes_per_sample": per_sample, "avg_launch_ms": ms_enc,
-                "note": "effective gather bandwidth against the reference's 16 384 B/sample; the collapsed table "
-                        "gathers 4 096 B/sample and most of it hits L2/Infinity Cache; the kernel's HBM traffic is "
-                        "dominated by the 512 B/sample feature write (see profiles/ PMC)"}
+                "frac": ach_g / hbm_peak_gbps, "traffic": traffic.get("encode_kernel"), "samples_per_launch": B,
+                "algorithmic_bytes_per_sample": hbm_per_sample, "avg_launch_ms": ms_enc,
+                "reference_equivalent": {"bytes_per_sample": per_sample, "GBps": B * per_sample / (ms_enc * 1e-3) / 1e9},
+                "note": "achieved = compulsory HBM bytes (feature write + aux + ray records) / launch time; traffic = "
+                        "FETCH+WRITE bytes per launch from the PMC profile (profiles/r01_pmc_traffic.json); "
+                        "reference_equivalent prices the same launch at the reference's 16 404 B/sample of gathers, "
+                        "which here hit L2/Infinity Cache (collapsed table: 4 096 B/sample gathered)"}
         ach_m = B * 754176 / (ms_mlp * 1e-3) / 1e12
         mlp = {"bound": "mfma", "kernel": "mlp_kernel (f16 MFMA, 3-term split, f32 accumulate)", "achieved": ach_m,
-               "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach_m / mfma_peak_tflops, "traffic": None,
-               "samples_per_launch": B, "algorithmic_flop_per_sample": 754176, "avg_launch_ms": ms_mlp,
-               "ray_hit_fraction": hit,
+               "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach_m / mfma_peak_tflops,
+               "traffic": traffic.get("mlp_kernel"), "samples_per_launch": B, "algorithmic_flop_per_sample": 754176,
+               "avg_launch_ms": ms_mlp, "ray_hit_fraction": hit, "issued_over_algorithmic": 3.0,
                "note": "algorithmic FLOPs = every sample of the frame x 754 176; the kernel issues 3 f16 MFMAs per "
-                       "algorithmic product (hi*hi + lo*hi + hi*lo) and skips 32-ray groups that hit nothing"}
+                       "algorithmic product (hi*hi + lo*hi + hi*lo: plain f16 misses the 1e-3 bound 17x) and skips "
+                       "32-ray groups that hit nothing; traffic = HBM bytes per launch from the PMC profile"}
         return mlp, grid
 
     # ------------------------------------------------------------------ row bands (tile-parallel single frame)
@@ -357,6 +366,17 @@ class Renderer:
             ev.mark("cnn")
             ev.done()
             return img
+
+
+def _profiled_traffic():
+    """HBM bytes per launch from the committed PMC profile (bench.py cannot run rocprofv3 on itself)."""
+    import json
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return {k: v["traffic"] for k, v in json.load(f)["per_launch_bytes"].items()}
+    except (OSError, KeyError, ValueError):
+        return {}
 
 
 def _time_ms(fn, reps=5):
