@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--samples", type=int, default=24)
     ap.add_argument("--scene-size", type=int, default=2048)
+    ap.add_argument("--apron", default="minimal", choices=["minimal", "reference"],
+                    help="field/CNN evaluated on the 4-px apron the image can depend on (bit-identical image), or on the "
+                         "reference's full 15-px apron")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     return ap.parse_args()
@@ -144,13 +147,13 @@ def main():
             dist.barrier()
 
     for k in range(args.warmup):
-        R.render_frame(frame_pose(k), hw, args.samples, mode=mode)
+        R.render_frame(frame_pose(k), hw, args.samples, mode=mode, apron=args.apron)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        img = R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode)
+        img = R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=args.apron)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -164,8 +167,19 @@ def main():
     # ---- per-stage breakdown + roofline of the dominant kernel (outside the timed region) ----------
     stages = {}
     for k in range(min(args.steps, 5)):
-        R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, timers=stages)
+        R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, timers=stages, apron=args.apron)
     stage_ms = {k: float(np.mean(v)) for k, v in stages.items()}
+    # the same frames with the other apron setting (outside the timed region; reported for transparency)
+    other = "reference" if args.apron == "minimal" else "minimal"
+    n_other = min(args.steps, 8)
+    for k in range(2):
+        R.render_frame(frame_pose(k), hw, args.samples, mode=mode, apron=other)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for k in range(n_other):
+        R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=other)
+    torch.cuda.synchronize()
+    other_ms = 1000.0 * (time.perf_counter() - t1) / n_other
     roof, roof_grid = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
 
     if rank == 0:
@@ -177,9 +191,15 @@ def main():
             "vs_baseline": None, "dtype": R.compute_dtype(mode), "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height}, num_samples={args.samples}, "
                                    f"scene_size={args.scene_size}, cam pattern 0 (every 2nd of 40 poses), "
-                                   f"1 frame per rank per step", "path": mode, "padded_rays": (hw[0] + 30) * (hw[1] + 30),
-                       "samples_per_frame": (hw[0] + 30) * (hw[1] + 30) * args.samples, "parallelism": f"frames x{world}"},
-            "stage_ms": stage_ms, "setup_s": setup_s,
+                                   f"1 frame per rank per step", "path": mode, "apron": args.apron,
+                       "padded_rays": (hw[0] + 30) * (hw[1] + 30),
+                       "field_rays": (hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30),
+                       "samples_per_frame": ((hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30)) * args.samples,
+                       "parallelism": f"frames x{world}",
+                       "apron_note": "ray casting and the sky MLP always cover the reference's padded frame (15-px apron); "
+                                     "'minimal' evaluates the field MLP and the CNN on the 4-px apron that can reach a kept "
+                                     "pixel -- the image is bit-identical (tests/test_render_gpu.py, test_fullsize_gpu.py)"},
+            "stage_ms": stage_ms, "setup_s": setup_s, f"ms_per_step_apron_{other}": other_ms,
             "roofline": roof, "roofline_grid_sampler": roof_grid,
         }
         if world == 1 and not args.no_cpu_baseline:

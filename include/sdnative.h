@@ -158,7 +158,8 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
  * Activations travel between the convolutions as two f16 planes (hi, lo) [cin/16 chunks][Hb*Wb][16 channels] with a zero
  * border (extent from sdn_conv_plane_dims; the caller zero-fills the planes ONCE, kernels never write the border or
  * pixels outside the H x W frame); fp32 tensors are rows [H*W][256] (channels last).
- *   y   = LeakyReLU_0.2( (resid + conv(in) + bias) * (mod_w + 1) + mod_b )       each term optional
+ *   y   = LeakyReLU_0.2( (resid + conv(in) + bias) * (mod_w + 1) + mod_b )       each term optional; the residual is
+ *         given either as fp32 rows (resid) or as hi/lo planes (resid_hi/lo, which MAY be the output planes: in place)
  *   img = tanh(proj_w . y + proj_b)                                                optional, [3][H*W]
  */
 void sdn_conv_plane_dims(int H, int W, int *Hb, int *Wb);
@@ -170,17 +171,21 @@ int sdn_conv_pack_weights(const float *w_oihw, int cin, int taps, void *packed, 
 int sdn_conv_planes_from_f32(const float *x, int channels, void *out_hi, void *out_lo, int H, int W, sdn_stream_t stream);
 /* outputs: any of (out_hi,out_lo) planes, out_f32 rows [H*W,256], out_img [3,H*W] (with proj_w [3,256], proj_b [3]) */
 int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void *packed, const float *bias,
-             const float *resid, const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32,
-             const float *proj_w, const float *proj_b, float *out_img, int H, int W, int n_workgroups, sdn_stream_t stream);
+             const float *resid, const void *resid_hi, const void *resid_lo, const float *mod_w, const float *mod_b,
+             void *out_hi, void *out_lo, float *out_f32, const float *proj_w, const float *proj_b, float *out_img, int H,
+             int W, int n_workgroups, sdn_stream_t stream);
 
 /* Sky MLP for every ray + per-feature sum over rays: SKYMLP.forward(positional_encoding(raydirs, 5, incl_orig), z)
- * (imaginaire/generators/gancraft_base.py:150-169; the frame mean of scenedreamer.py:592-598 = sky_sum / n_rays).
+ * (imaginaire/generators/gancraft_base.py:150-169; the frame mean of scenedreamer.py:592-598 = column sums of sky_partial / n_rays).
  * consts (sdn_sky_consts_floats floats): [fc1.bias + fc_z_a(z) : 256][fc2..fc5 bias : 4x256][fc_out_c.bias : 64];
- * w1 dev [256,33]; wh4_host host array of 4 dev pointers [256,256]; wc dev [64,256]; sky_sum dev [64] pre-zeroed. */
+ * w1 dev [256,33]; wh4_host host array of 4 dev pointers [256,256]; wc dev [64,256];
+ * sky_partial dev f32 [sdn_sky_partial_rows(n_rays, n_workgroups), 64]: every wave's sum of its rays' sky_c (all rows are
+ * written; the caller adds them up -- no float atomics, the mean is reproducible bit for bit). */
+int32_t sdn_sky_partial_rows(int32_t n_rays, int32_t n_workgroups);
 size_t sdn_sky_packed_weight_bytes(void);
 size_t sdn_sky_consts_floats(void);
 int sdn_sky_pack_weights(const float *w1, const float *const *wh4_host, const float *wc, void *packed, sdn_stream_t stream);
-int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_sum, int32_t n_rays,
+int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_partial, int32_t n_rays,
                 int32_t n_workgroups, sdn_stream_t stream);
 
 /* test hook: C[32,32] = A[32,16] * B[16,32] through the MFMA operand layouts field.hip relies on */

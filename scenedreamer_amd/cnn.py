@@ -37,18 +37,28 @@ class MfmaCNN:
             capi.lib().sdn_conv_plane_dims(H, W, ctypes.byref(hb), ctypes.byref(wb))
             n = hb.value * wb.value * 256
             mk = lambda: torch.zeros(n, dtype=torch.float16, device=self.R.dev)   # zero border / out-of-frame pixels
-            self._planes.clear()
-            self._planes[key] = dict(a=(mk(), mk()), b=(mk(), mk()),
-                                     y0=torch.empty(H * W, 256, device=self.R.dev),
-                                     y1=torch.empty(H * W, 256, device=self.R.dev))
+            while len(self._planes) >= 2:
+                self._planes.pop(next(iter(self._planes)))
+            self._planes[key] = dict(a=(mk(), mk()), b=(mk(), mk()))
         return self._planes[key]
 
-    def _conv(self, src, name, H, W, bias=None, resid=None, mod=None, dst=None, out32=None, proj=None, img=None):
+    def _adapt(self):
+        """The four FiLM vectors of the current style (gancraft_base.py:204), cached per cnn_adapt tensor."""
+        t = self.R.cnn_adapt
+        if getattr(self, "_adapt_src", None) is not t:
+            self._adapt_src = t
+            self._adapt_vecs = [c[0].contiguous() for c in torch.chunk(t, 4, dim=-1)]
+        return self._adapt_vecs
+
+    def _conv(self, src, name, H, W, bias=None, resid=None, resid_planes=None, mod=None, dst=None, out32=None, proj=None,
+              img=None):
         p = lambda t: t.data_ptr() if t is not None else None
         cin, taps = _LAYERS[name]
         with torch.cuda.device(self.R.dev):
             capi.check(capi.lib().sdn_conv(src[0].data_ptr(), src[1].data_ptr(), cin, taps, self.packed[name].data_ptr(),
-                                           p(bias), p(resid), p(mod[0]) if mod else None, p(mod[1]) if mod else None,
+                                           p(bias), p(resid), resid_planes[0].data_ptr() if resid_planes else None,
+                                           resid_planes[1].data_ptr() if resid_planes else None,
+                                           p(mod[0]) if mod else None, p(mod[1]) if mod else None,
                                            dst[0].data_ptr() if dst else None, dst[1].data_ptr() if dst else None, p(out32),
                                            p(proj[0]) if proj else None, p(proj[1]) if proj else None, p(img),
                                            H, W, 0, capi.current_stream(self.R.dev)), "sdn_conv")
@@ -58,19 +68,21 @@ class MfmaCNN:
         R, w = self.R, self.R.w
         _, H, W, _ = net_out.shape
         buf = self._buffers(H, W)
-        A, B, y0, y1 = buf["a"], buf["b"], buf["y0"], buf["y1"]
-        a = [t[0].contiguous() for t in torch.chunk(R.cnn_adapt, 4, dim=-1)]
+        A, B = buf["a"], buf["b"]
+        a = self._adapt()
         bias = lambda n: w.get(f"denoiser.{n}.bias")
         x = net_out.reshape(H * W, 64).contiguous()
         img = torch.empty(1, 3, H, W, device=R.dev)
         with torch.cuda.device(R.dev):
             capi.check(capi.lib().sdn_conv_planes_from_f32(x.data_ptr(), 64, B[0].data_ptr(), B[1].data_ptr(), H, W,
                                                            capi.current_stream(R.dev)), "sdn_conv_planes_from_f32")
-        self._conv(B, "conv1", H, W, bias=bias("conv1"), dst=A, out32=y0)                          # y0 = act(conv1(x))
-        self._conv(A, "conv2a", H, W, bias=bias("conv2a"), dst=B)                                  # act(conv2a(y0))
-        self._conv(B, "conv2b", H, W, bias=bias("conv2b"), resid=y0, mod=(a[0], a[1]), dst=A, out32=y1)
+        # the running activation y lives in planes A (hi + lo f16 = y to 2^-22) and is updated in place by the
+        # residual convolutions; planes B hold the inner activation of each residual block
+        self._conv(B, "conv1", H, W, bias=bias("conv1"), dst=A)                                    # y = act(conv1(x))
+        self._conv(A, "conv2a", H, W, bias=bias("conv2a"), dst=B)                                  # act(conv2a(y))
+        self._conv(B, "conv2b", H, W, bias=bias("conv2b"), resid_planes=A, mod=(a[0], a[1]), dst=A)
         self._conv(A, "conv3a", H, W, bias=bias("conv3a"), dst=B)
-        self._conv(B, "conv3b", H, W, bias=bias("conv3b"), resid=y1, mod=(a[2], a[3]), dst=A, out32=y0)
+        self._conv(B, "conv3b", H, W, bias=bias("conv3b"), resid_planes=A, mod=(a[2], a[3]), dst=A)
         self._conv(A, "conv4a", H, W, bias=bias("conv4a"), dst=B)
-        self._conv(B, "conv4b", H, W, bias=bias("conv4b"), resid=y0, proj=(self.w4, self.b4), img=img)
+        self._conv(B, "conv4b", H, W, bias=bias("conv4b"), resid_planes=A, proj=(self.w4, self.b4), img=img)
         return img

@@ -54,6 +54,7 @@ struct ConvParams {
     int ksteps;                // TAPS * (input channels / 16)
     const float *bias;         // [256] or nullptr
     const float *resid;        // fp32 [H*W][256] or nullptr
+    const _Float16 *rh, *rl;   // residual as hi/lo planes (same layout as the output planes; may alias them) or nullptr
     const float *mod_w;        // [256] FiLM scale (applied as w + 1) or nullptr
     const float *mod_b;        // [256]
     _Float16 *oh, *ol;         // output planes or nullptr
@@ -275,6 +276,12 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                     if (p.resid) {   // y = y + conv(...)   (gancraft_base.py:213, :216)
                         const float4 r = *reinterpret_cast<const float4 *>(p.resid + orow * CH + c0);
                         v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
+                    } else if (p.rh) {   // the same, y kept as hi + lo planes (exact to 2^-22; read before the in-place store)
+                        const long ro = ((long)(c0 >> 4) * ((long)p.Hb * p.Wb) + ppix) * 16 + (c0 & 15);
+                        const half4 h4 = *reinterpret_cast<const half4 *>(p.rh + ro);
+                        const half4 l4 = *reinterpret_cast<const half4 *>(p.rl + ro);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) v[e] = ((float)h4[e] + (float)l4[e]) + v[e];
                     }
                     if (p.mod_w) {   // modulate: x * (w + 1) + b   (:197-200)
                         const float4 mw = *reinterpret_cast<const float4 *>(p.mod_w + c0);
@@ -405,18 +412,21 @@ int sdn_conv_planes_from_f32(const float *x, int channels, void *out_hi, void *o
 }
 
 int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void *packed, const float *bias, const float *resid,
-             const float *mod_w, const float *mod_b, void *out_hi, void *out_lo, float *out_f32, const float *proj_w,
-             const float *proj_b, float *out_img, int H, int W, int n_workgroups, sdn_stream_t stream) {
+             const void *resid_hi, const void *resid_lo, const float *mod_w, const float *mod_b, void *out_hi, void *out_lo,
+             float *out_f32, const float *proj_w, const float *proj_b, float *out_img, int H, int W, int n_workgroups,
+             sdn_stream_t stream) {
     SDN_REQUIRE(in_hi && in_lo && packed && H > 0 && W > 0, "sdn_conv: bad argument");
     SDN_REQUIRE(conv_shape_ok(cin, taps), "sdn_conv: supported shapes are 3x3 256->256 and 1x1 (64..256, multiple of 16)->256");
     SDN_REQUIRE((out_hi && out_lo) || out_f32 || out_img, "sdn_conv: no output requested");
     SDN_REQUIRE((mod_w == nullptr) == (mod_b == nullptr), "sdn_conv: mod_w and mod_b go together");
+    SDN_REQUIRE((resid_hi == nullptr) == (resid_lo == nullptr) && !(resid && resid_hi), "sdn_conv: one residual form at most");
+    SDN_REQUIRE(!(resid_hi && (resid_hi == in_hi || resid_lo == in_lo)), "sdn_conv: the residual planes must not be the input planes");
     SDN_REQUIRE((proj_w == nullptr) == (out_img == nullptr) && (proj_w == nullptr) == (proj_b == nullptr),
                 "sdn_conv: proj_w, proj_b and out_img go together");
     ConvParams p;
     p.xh = (const _Float16 *)in_hi; p.xl = (const _Float16 *)in_lo; p.wpk = (const char *)packed;
     p.ksteps = (cin / 16) * taps;
-    p.bias = bias; p.resid = resid; p.mod_w = mod_w; p.mod_b = mod_b;
+    p.bias = bias; p.resid = resid; p.rh = (const _Float16 *)resid_hi; p.rl = (const _Float16 *)resid_lo; p.mod_w = mod_w; p.mod_b = mod_b;
     p.oh = (_Float16 *)out_hi; p.ol = (_Float16 *)out_lo; p.of32 = out_f32;
     p.proj_w = proj_w; p.proj_b = proj_b; p.img = out_img;
     p.H = H; p.W = W;

@@ -1017,8 +1017,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
 // =====================================================================================================
 // Same machinery as mlp_kernel (transposed register-resident chain, 3-term f16 split, LDS weight ring):
 // 32 rays per wave, layers 33(->64 padded) -> 256 -> 256 x4 -> 64.  The style term fc_z_a(z) is folded into fc1's
-// bias on the host.  The per-feature sum over rays (for sky_avg) is reduced per wave and added with one atomic
-// per feature per wave.
+// bias on the host.  The per-feature sum over rays (for sky_avg) is reduced per wave and written as one row of
+// partial sums per wave (added up by the caller in a fixed order: reproducible, unlike float atomics).
 constexpr int SKY_IN = 33, SKY_K0 = 64;                       // encoded ray direction, padded to 4 k-steps
 constexpr int SKY_SLOTS = 4 + 4 * 16 + 4;                     // 72
 constexpr size_t SKY_L0_FRAGS = 16 * 4 * 64;                  // 16 units
@@ -1033,7 +1033,8 @@ struct SkyParams {
     const half8 *wpk;
     const float *consts;    // SC_TOTAL floats
     float *sky_c;           // [R,64]
-    float *sky_sum;         // [64], pre-zeroed by the caller; sum over rays of sky_c
+    float *sky_partial;     // [4 * gridDim.x][64]: every wave's sum of sky_c over its rays (summed by the caller: no float
+                            // atomics, so the frame mean is reproducible bit for bit)
     int32_t R, n_tiles;
 };
 
@@ -1175,7 +1176,8 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
 #pragma unroll
         for (int ib = 0; ib < 2; ib++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) atomicAdd(p.sky_sum + 32 * ib + 8 * q + 4 * h + e, fsum[ib][e]);
+            for (int e = 0; e < 4; e++)
+                p.sky_partial[(size_t)(blockIdx.x * 4 + wave) * OUTC + 32 * ib + 8 * q + 4 * h + e] = fsum[ib][e];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1376,16 +1378,22 @@ int sdn_sky_pack_weights(const float *w1, const float *const *wh4_host, const fl
     return sdn::check_launch("sdn_sky_pack_weights");
 }
 
-int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_sum, int32_t n_rays,
+static int sky_workgroups(int32_t n_rays, int32_t n_workgroups) {
+    int wg = n_workgroups > 0 ? n_workgroups : 256;
+    const int groups = sdn::div_up(sdn::div_up(n_rays, 32), 4);
+    return wg > groups ? groups : wg;
+}
+
+int32_t sdn_sky_partial_rows(int32_t n_rays, int32_t n_workgroups) { return n_rays > 0 ? 4 * sky_workgroups(n_rays, n_workgroups) : 0; }
+
+int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_partial, int32_t n_rays,
                 int32_t n_workgroups, sdn_stream_t stream) {
-    SDN_REQUIRE(raydirs && packed && consts && sky_c && sky_sum && n_rays > 0, "sdn_sky_mlp: bad argument");
+    SDN_REQUIRE(raydirs && packed && consts && sky_c && sky_partial && n_rays > 0, "sdn_sky_mlp: bad argument");
     SkyParams p;
-    p.raydirs = raydirs; p.wpk = (const half8 *)packed; p.consts = consts; p.sky_c = sky_c; p.sky_sum = sky_sum;
+    p.raydirs = raydirs; p.wpk = (const half8 *)packed; p.consts = consts; p.sky_c = sky_c; p.sky_partial = sky_partial;
     p.R = n_rays;
     p.n_tiles = sdn::div_up(n_rays, 32);
-    int wg = n_workgroups > 0 ? n_workgroups : 256;
-    const int groups = sdn::div_up(p.n_tiles, 4);
-    if (wg > groups) wg = groups;
+    const int wg = sky_workgroups(n_rays, n_workgroups);
     hipLaunchKernelGGL(sky_kernel<0>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_sky_mlp");
 }

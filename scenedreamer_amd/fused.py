@@ -71,7 +71,8 @@ def _buffers(R, n_rays, ns):
     cache = R.__dict__.setdefault("_fused_buf", {})
     if key not in cache:
         lib = _lib()
-        cache.clear()
+        while len(cache) >= 2:      # e.g. the two apron settings of one resolution; older shapes are dropped
+            cache.pop(next(iter(cache)))
         aux = lib.sdn_field_aux_elems(n_rays, ns)
         cache[key] = dict(
             feat=torch.empty(lib.sdn_field_feat_bytes(n_rays, ns) // 4, dtype=torch.float32, device=R.dev),
@@ -170,8 +171,8 @@ def sky_fused(R, rd):
     rd = rd.contiguous()
     n = rd.shape[0]
     sky_c = torch.empty((n, 64), dtype=torch.float32, device=R.dev)
-    ssum = torch.zeros(64, dtype=torch.float32, device=R.dev)
+    part = torch.empty((_lib().sdn_sky_partial_rows(n, 0), 64), dtype=torch.float32, device=R.dev)
     with torch.cuda.device(R.dev):
         capi.check(_lib().sdn_sky_mlp(rd.data_ptr(), sk["packed"].data_ptr(), sk["consts"].data_ptr(), sky_c.data_ptr(),
-                                      ssum.data_ptr(), n, 0, _stream(R.dev)), "sdn_sky_mlp")
-    return sky_c, (ssum / n).reshape(1, 64)
+                                      part.data_ptr(), n, 0, _stream(R.dev)), "sdn_sky_mlp")
+    return sky_c, (part.sum(dim=0, dtype=torch.float64) / n).to(torch.float32).reshape(1, 64)

@@ -314,8 +314,15 @@ class Renderer:
 
     # ------------------------------------------------------------------ frame
     def render_frame(self, pose, resolution_hw=(540, 960), num_samples=24, mode="unfused", cnn=True,
-                     ray_chunk=1 << 16, timers=None, cnn_mode=None):
-        """One frame of the trajectory.  Returns image [1,3,H,W] (or net_out [1,Hp,Wp,64] if cnn=False)."""
+                     ray_chunk=1 << 16, timers=None, cnn_mode=None, apron="minimal"):
+        """One frame of the trajectory.  Returns image [1,3,H,W] (or net_out [1,Hp,Wp,64] if cnn=False).
+
+        apron: the reference evaluates every ray of the frame padded by 15 px per side (its tile scheme,
+        scenedreamer.py:573-628) and crops the image afterwards.  Only CNN_HALO = 4 px of that apron can reach a kept
+        pixel (RenderCNN has four 3x3 convolutions, gancraft_base.py:175-225; their zero padding at the padded frame's
+        border is 15 px away).  "minimal" (fused path, default) evaluates the field and the CNN on the 4-px apron; the
+        sky MLP still sees every ray of the padded frame, because its frame mean does (scenedreamer.py:592-598).  The
+        image is bit-identical to "reference" (full apron) -- tests/test_render_gpu.py."""
         ev = _Stamps(timers)
         with torch.no_grad():
             ev.mark("start")
@@ -334,6 +341,15 @@ class Renderer:
                 sky_c = self.sky_features(rd)
                 sky_avg = sky_c.mean(dim=0, keepdim=True)    # full-frame mean, scenedreamer.py:592-598
             ev.mark("sky")
+            crop = self.pad // 2
+            if mode == "fused" and cnn and apron == "minimal" and crop > CNN_HALO:
+                o = crop - CNN_HALO     # rows / columns of the padded frame that cannot influence the cropped image
+                vid = vid.view(Hp, Wp, self.M)[o:Hp - o, o:Wp - o].reshape(-1, self.M)
+                d2 = d2.view(2, Hp, Wp, self.M)[:, o:Hp - o, o:Wp - o].reshape(2, -1, self.M)
+                rd = rd.view(Hp, Wp, 3)[o:Hp - o, o:Wp - o].reshape(-1, 3)
+                sky_c = sky_c.view(Hp, Wp, 64)[o:Hp - o, o:Wp - o].reshape(-1, 64)
+                Hp, Wp, crop = Hp - 2 * o, Wp - 2 * o, CNN_HALO
+                R = Hp * Wp
             if mode == "unfused":
                 outs = []
                 for r0 in range(0, R, ray_chunk):
@@ -360,12 +376,14 @@ class Renderer:
                 img = self._mfma_cnn(net_out)
             else:
                 img = self.render_cnn(net_out)
-            p = self.pad // 2
-            if self.pad:
-                img = img[:, :, p:-p, p:-p]
+            if crop:
+                img = img[:, :, crop:-crop, crop:-crop]
             ev.mark("cnn")
             ev.done()
             return img
+
+
+CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (conv2a, conv2b, conv3a, conv3b)
 
 
 def _profiled_traffic():

@@ -64,6 +64,13 @@ def test_rvip_skipping_is_exact_at_full_size(big):
         assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
 
 
+def test_minimal_apron_is_bit_identical_at_full_size(big):
+    R, scene, poses = big
+    a = R.render_frame(poses[9], (540, 960), 24, mode="fused", apron="minimal")
+    b = R.render_frame(poses[9], (540, 960), 24, mode="fused", apron="reference")
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("hw,ns,pi", [((540, 960), 24, 4), ((1080, 1920), 40, 12)])
 def test_fused_and_unfused_frames_agree_at_full_size(big, hw, ns, pi):
     R, scene, poses = big

@@ -92,6 +92,17 @@ def test_full_frame_equals_reference_tiling(renderer, weights_full, scene256, lu
     assert err.max() < TOL, f"image max abs err {err.max():.3e}"
 
 
+def test_minimal_apron_is_bit_identical(renderer, scene256):
+    """Evaluating the field / CNN on the 4-px apron the image can depend on == evaluating the reference's 15-px apron."""
+    from scenedreamer_amd import camera
+    for pi, hw in ((1, (96, 80)), (6, (61, 133))):
+        pose = camera.eval_camera_poses(scene256, maxstep=8)[pi]
+        a = renderer.render_frame(pose, hw, 12, mode="fused", apron="minimal")
+        b = renderer.render_frame(pose, hw, 12, mode="fused", apron="reference")
+        assert a.shape == b.shape == (1, 3, hw[0], hw[1])
+        assert torch.equal(a, b)
+
+
 def test_mfma_cnn_matches_torch_cnn(renderer):
     """RenderCNN on the MFMA 3x3 kernels vs the same network through PyTorch/MIOpen fp32, frame with ragged edges."""
     from scenedreamer_amd.cnn import MfmaCNN

@@ -17,8 +17,8 @@ buf = cnn._buffers(H, W)
 t_all = _time_ms(lambda: cnn(x), 5)
 t_conv = _time_ms(lambda: cnn._conv(buf["a"], "conv2a", H, W, bias=R.w["denoiser.conv2a.bias"], dst=buf["b"]), 5)
 t_11 = _time_ms(lambda: cnn._conv(buf["a"], "conv4a", H, W, bias=R.w["denoiser.conv4a.bias"], dst=buf["b"]), 5)
-t_1 = _time_ms(lambda: cnn._conv(buf["b"], "conv1", H, W, bias=R.w["denoiser.conv1.bias"], dst=buf["a"], out32=buf["y0"]), 5)
+t_1 = _time_ms(lambda: cnn._conv(buf["b"], "conv1", H, W, bias=R.w["denoiser.conv1.bias"], dst=buf["a"]), 5)
 img = torch.empty(1, 3, H, W, device=dev)
-t_4b = _time_ms(lambda: cnn._conv(buf["b"], "conv4b", H, W, bias=R.w.get("denoiser.conv4b.bias"), resid=buf["y0"], proj=(cnn.w4, cnn.b4), img=img), 5)
+t_4b = _time_ms(lambda: cnn._conv(buf["b"], "conv4b", H, W, bias=R.w.get("denoiser.conv4b.bias"), resid_planes=buf["a"], proj=(cnn.w4, cnn.b4), img=img), 5)
 print(f"conv1 {t_1:.3f} ms  conv4a {t_11:.3f} ms  conv4b+proj {t_4b:.3f} ms")
 print(f"cnn total {t_all:.3f} ms   one conv3x3 {t_conv:.3f} ms   dbg={os.environ.get('SDN_CONV_DBG','0')}")
