@@ -151,9 +151,12 @@ def main():
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for k in range(args.steps):
         img = R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=args.apron)
+        marks[k + 1].record()       # no sync: per-frame device times for the p10 / p50 / p90 spread (DDA work is pose dependent)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -163,6 +166,21 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    frame_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    pct = lambda q: frame_ms[min(len(frame_ms) - 1, int(round(q * (len(frame_ms) - 1))))]
+
+    # ---- delivered rate: frame in host memory as uint8 HWC (async D2H, PNG/MP4 encoding excluded), outside the timed region
+    from scenedreamer_amd.output import to_uint8_hwc
+    n_del = min(args.steps, 10)
+    pinned = [torch.empty((hw[0], hw[1], 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for k in range(n_del):
+        im = R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=args.apron)
+        pinned[k & 1].copy_(to_uint8_hwc(im), non_blocking=True)
+    torch.cuda.synchronize()
+    delivered_fps = n_del / (time.perf_counter() - t2)
 
     # ---- per-stage breakdown + roofline of the dominant kernel (outside the timed region) ----------
     stages = {}
@@ -199,6 +217,7 @@ def main():
                        "apron_note": "ray casting and the sky MLP always cover the reference's padded frame (15-px apron); "
                                      "'minimal' evaluates the field MLP and the CNN on the 4-px apron that can reach a kept "
                                      "pixel -- the image is bit-identical (tests/test_render_gpu.py, test_fullsize_gpu.py)"},
+            "frame_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "delivered_frames_per_s_uint8_host": delivered_fps,
             "stage_ms": stage_ms, "setup_s": setup_s, f"ms_per_step_apron_{other}": other_ms,
             "roofline": roof, "roofline_grid_sampler": roof_grid,
         }

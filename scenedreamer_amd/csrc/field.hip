@@ -312,6 +312,11 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
     }
     const float d0 = p.raydirs[(size_t)rr * 3], d1 = p.raydirs[(size_t)rr * 3 + 1], d2 = p.raydirs[(size_t)rr * 3 + 2];
     bool gnd = false;
+    // A ray that hits nothing gets weight 0 for all its samples (scenedreamer.py:376: weights * (1 - sky_only)), so
+    // its features are never used: no gathers for its lanes, and no feature traffic at all for a tile of 8 such rays
+    // (the MLP kernel reads whatever is there and discards the result by selection, not multiplication).
+    const bool use_feat = ray_ok && rb.id[0] != 0;
+    const bool tile_dead = !__any(use_feat);
 
     for (int ch = 0; ch < p.nch; ch++) {
         const int sidx = ch * SAMP_PER_STEP + (j & 3);
@@ -335,12 +340,13 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
                 if (k == pl.idx) id = rb.id[k];
             p.label[tc * 32 + j] = p.lut[id & 1023];
         }
+        if (tile_dead) continue;
         float *fout = p.feat + (tc * 8 * 64 + lane) * 8;
 #pragma unroll 2
         for (int s = 0; s < 8; s++) {
             const int level = 2 * s + h;
             float res[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (!oob && valid) {
+            if (!oob && valid && use_feat) {
                 const float scale = p.scales[level];
                 float f0 = mul_add_exact(x0, scale, 0.5f), f1 = mul_add_exact(x1, scale, 0.5f),
                       f2 = mul_add_exact(x2, scale, 0.5f);

@@ -36,7 +36,11 @@ def broadcast_large(t, src=0, min_numel=1 << 20):
     rank = dist.get_rank()
     mine = torch.empty(chunk, dtype=t.dtype, device=t.device)
     parts = [flat[i * chunk:(i + 1) * chunk].contiguous() for i in range(world)] if rank == src else None
-    dist.scatter(mine, parts, src=src)
+    try:
+        dist.scatter(mine, parts, src=src)
+    except (RuntimeError, NotImplementedError):   # a backend without scatter: every rank takes the plain broadcast
+        dist.broadcast(t, src)
+        return t
     outs = [torch.empty(chunk, dtype=t.dtype, device=t.device) for _ in range(world)]
     dist.all_gather(outs, mine)
     if rank != src:
