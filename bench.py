@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--apron", default="minimal", choices=["minimal", "reference"],
                     help="field/CNN evaluated on the 4-px apron the image can depend on (bit-identical image), or on the "
                          "reference's full 15-px apron")
+    ap.add_argument("--no-overlap", action="store_true", help="do not cast the next frame's rays on a second stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget-s", type=float, default=20.0)
     return ap.parse_args()
@@ -154,8 +155,12 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     marks[0].record()
-    for k in range(args.steps):
-        img = R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=args.apron)
+    timed_poses = [frame_pose(args.warmup + k) for k in range(args.steps)]
+    if args.no_overlap or mode != "fused":
+        frames = (R.render_frame(pz, hw, args.samples, mode=mode, apron=args.apron) for pz in timed_poses)
+    else:   # all K frames are cast, evaluated and finished inside the timed region; frame k+1's ray casting runs beside frame k
+        frames = R.render_frames(timed_poses, hw, args.samples, mode=mode, apron=args.apron)
+    for k, img in enumerate(frames):
         marks[k + 1].record()       # no sync: per-frame device times for the p10 / p50 / p90 spread (DDA work is pose dependent)
     torch.cuda.synchronize()
     barrier()
@@ -210,6 +215,7 @@ def main():
             "config": {"workload": f"{args.width}x{args.height}, num_samples={args.samples}, "
                                    f"scene_size={args.scene_size}, cam pattern 0 (every 2nd of 40 poses), "
                                    f"1 frame per rank per step", "path": mode, "apron": args.apron,
+                       "ray_casting_overlap": not (args.no_overlap or mode != "fused"),
                        "padded_rays": (hw[0] + 30) * (hw[1] + 30),
                        "field_rays": (hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30),
                        "samples_per_frame": ((hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30)) * args.samples,

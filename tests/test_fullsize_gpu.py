@@ -64,6 +64,15 @@ def test_rvip_skipping_is_exact_at_full_size(big):
         assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
 
 
+def test_pipelined_trajectory_equals_frame_by_frame(big):
+    """render_frames (ray casting of frame i+1 on a second stream beside frame i) yields the same bits as render_frame."""
+    R, scene, poses = big
+    sel = [poses[i] for i in (2, 11, 23, 30)]
+    piped = [im.clone() for im in R.render_frames(sel, (540, 960), 24, mode="fused")]
+    for pose, im in zip(sel, piped):
+        assert torch.equal(im, R.render_frame(pose, (540, 960), 24, mode="fused"))
+
+
 def test_minimal_apron_is_bit_identical_at_full_size(big):
     R, scene, poses = big
     a = R.render_frame(poses[9], (540, 960), 24, mode="fused", apron="minimal")
