@@ -100,19 +100,28 @@ def encode(R, vid, d2, rd, cam_ori, ns, buf=None):
     return buf
 
 
+FEATURE_BUFFER_BYTES = 32 << 30   # rays are processed in chunks whose encode -> mlp feature buffer stays below this
+
+
 def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns):
-    """net_out [R,64] for intersections vid [R,M] / d2 [2,R,M] / raydirs rd [R,3]."""
+    """net_out [R,64] for intersections vid [R,M] / d2 [2,R,M] / raydirs rd [R,3].
+    Rays are independent, so very large frames (4K x 40 samples = 174 GB of features) go through in ray chunks that
+    reuse one feature buffer; the headline frame (6.9 GB) is a single chunk."""
     st = R._fused_style or prepare_style(R)
-    vid, d2, rd, sky_c = vid.contiguous(), d2.contiguous(), rd.contiguous(), sky_c.contiguous()
     n_rays = vid.shape[0]
-    buf = encode(R, vid, d2, rd, cam_ori, ns)
     st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
     net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
-    with torch.cuda.device(R.dev):
-        rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                  buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
-                                  sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, 0, _stream(R.dev))
-    capi.check(rc, "sdn_field_mlp")
+    per_ray = _lib().sdn_field_feat_bytes(32, ns) // 32
+    chunk = max(32, (FEATURE_BUFFER_BYTES // per_ray) // 32 * 32)     # whole 32-ray groups
+    for r0 in range(0, n_rays, chunk):
+        r1 = min(n_rays, r0 + chunk)
+        v, d, r_, s_ = vid[r0:r1].contiguous(), d2[:, r0:r1].contiguous(), rd[r0:r1].contiguous(), sky_c[r0:r1].contiguous()
+        buf = encode(R, v, d, r_, cam_ori, ns)
+        with torch.cuda.device(R.dev):
+            rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
+                                      buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
+                                      s_.data_ptr(), net_out[r0:r1].data_ptr(), r1 - r0, ns, 0, _stream(R.dev))
+        capi.check(rc, "sdn_field_mlp")
     return net_out
 
 

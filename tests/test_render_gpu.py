@@ -103,6 +103,16 @@ def test_minimal_apron_is_bit_identical(renderer, scene256):
         assert torch.equal(a, b)
 
 
+def test_ray_chunking_is_bit_identical(renderer, scene256, monkeypatch):
+    """Frames whose feature buffer would not fit go through the field in ray chunks: same bits as one pass."""
+    from scenedreamer_amd import camera, fused
+    pose = camera.eval_camera_poses(scene256, maxstep=8)[3]
+    a = renderer.render_frame(pose, (64, 72), 12, mode="fused")
+    monkeypatch.setattr(fused, "FEATURE_BUFFER_BYTES", 12 * 512 * 1000)      # ~1000 rays per chunk -> 6 chunks, ragged last
+    b = renderer.render_frame(pose, (64, 72), 12, mode="fused")
+    assert torch.equal(a, b)
+
+
 def test_mfma_cnn_matches_torch_cnn(renderer):
     """RenderCNN on the MFMA 3x3 kernels vs the same network through PyTorch/MIOpen fp32, frame with ragged edges."""
     from scenedreamer_amd.cnn import MfmaCNN

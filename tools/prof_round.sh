@@ -3,7 +3,9 @@
 #   bash tools/prof_round.sh <tag>     -> gpurun_out/<tag>_*.md
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O; P=/tmp/prof_$1; T=$1
-rocprofv3 --kernel-trace --stats -d $P/k -o k -- python $R/tools/frame_once.py fused 8 > $O/prof.log 2>&1
+# the kernel trace is taken on bench.py itself (the command whose JSON line is reported); MIOPEN_FIND_MODE=FAST keeps MIOpen's
+# one-off exhaustive search for the per-scene world-encoder convolutions (seconds of naive_conv kernels) out of the table
+MIOPEN_FIND_MODE=FAST rocprofv3 --kernel-trace --stats -d $P/k -o k -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/${T}_bench_under_rocprof.json 2> $O/prof.log
 python $R/tools/rocpd_stats.py $P/k/k_results.db 24 > $O/${T}_kernel_stats.md
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $P/f -o f -- python $R/tools/frame_once.py fused 3 >> $O/prof.log 2>&1
 python $R/tools/rocpd_stats.py $P/f/f_results.db 8 _kernel > $O/${T}_pmc_fetch.md
