@@ -241,13 +241,14 @@ class Renderer:
         # (84 B / ray); the 8-corner gather (4 096 B/sample of the collapsed table, 16 384 B in the reference) is served
         # by L2 / Infinity Cache.  `achieved` prices the kernel against what it must move through HBM; the
         # reference-equivalent gather rate (16 404 B/sample) is reported beside it.
-        hbm_per_sample = 512 + 5 + 84.0 / num_samples
+        # features are only written for rays that hit something (ray-level hit fraction; the kernel skips whole 8-ray tiles)
+        hbm_per_sample = 512 * hit + 5 + 84.0 / num_samples
         ach_g = B * hbm_per_sample / (ms_enc * 1e-3) / 1e9
         grid = {"bound": "hbm", "kernel": kernel, "achieved": ach_g, "peak": hbm_peak_gbps, "unit": "GB/s",
                 "frac": ach_g / hbm_peak_gbps, "traffic": traffic.get("encode_kernel"), "samples_per_launch": B,
                 "algorithmic_bytes_per_sample": hbm_per_sample, "avg_launch_ms": ms_enc,
                 "reference_equivalent": {"bytes_per_sample": per_sample, "GBps": B * per_sample / (ms_enc * 1e-3) / 1e9},
-                "note": "achieved = compulsory HBM bytes (feature write + aux + ray records) / launch time; traffic = "
+                "note": "achieved = compulsory HBM bytes (feature write for rays that hit + aux + ray records) / launch time; traffic = "
                         "FETCH+WRITE bytes per launch from the PMC profile (profiles/r01_pmc_traffic.json); "
                         "reference_equivalent prices the same launch at the reference's 16 404 B/sample of gathers, "
                         "which here hit L2/Infinity Cache (collapsed table: 4 096 B/sample gathered)"}
