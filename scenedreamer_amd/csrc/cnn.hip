@@ -263,52 +263,68 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
             const long orow = (long)py * p.W + px;                          // fp32 rows are unpadded
             const long ppix = (long)(py + 1) * p.Wb + (px + 1);             // padded pixel index
             float pj[3] = {0.f, 0.f, 0.f};
+            const long plane_px = (long)p.Hb * p.Wb;
+            // The packed weights permute the rows of every 32-channel block (pack_conv_kernel) so that accumulator
+            // register r of half-wave h is channel 32*ib + 16*h + r: a lane owns one whole 16-channel chunk of its pixel
+            // per row block = 32 contiguous bytes of each plane, and the 8 pixels of a tile row are 256 contiguous bytes.
 #pragma unroll
             for (int ib = 0; ib < 8; ib++) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; g4++) {
-                    const int c0 = 32 * ib + 8 * g4 + 4 * h;                // 4 consecutive channels
-                    float v[4] = {acc[ib][4 * g4], acc[ib][4 * g4 + 1], acc[ib][4 * g4 + 2], acc[ib][4 * g4 + 3]};
-                    if (p.bias) {
-                        const float4 b = *reinterpret_cast<const float4 *>(p.bias + c0);
-                        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-                    }
-                    if (p.resid) {   // y = y + conv(...)   (gancraft_base.py:213, :216)
-                        const float4 r = *reinterpret_cast<const float4 *>(p.resid + orow * CH + c0);
-                        v[0] = r.x + v[0]; v[1] = r.y + v[1]; v[2] = r.z + v[2]; v[3] = r.w + v[3];
-                    } else if (p.rh) {   // the same, y kept as hi + lo planes (exact to 2^-22; read before the in-place store)
-                        const long ro = ((long)(c0 >> 4) * ((long)p.Hb * p.Wb) + ppix) * 16 + (c0 & 15);
-                        const half4 h4 = *reinterpret_cast<const half4 *>(p.rh + ro);
-                        const half4 l4 = *reinterpret_cast<const half4 *>(p.rl + ro);
+                for (int q = 0; q < 2; q++) {
+                    const int c0 = 32 * ib + 16 * h + 8 * q;                 // 8 consecutive channels
+                    float v[8];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) v[e] = ((float)h4[e] + (float)l4[e]) + v[e];
+                    for (int e = 0; e < 8; e++) v[e] = acc[ib][8 * q + e];
+                    if (p.bias) {
+                        const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + c0), b1 = *reinterpret_cast<const float4 *>(p.bias + c0 + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    const long po = ((long)(2 * ib + h) * plane_px + ppix) * 16 + 8 * q;   // element offset inside a plane
+                    if (p.resid) {   // y = y + conv(...)   (gancraft_base.py:213, :216)
+                        const float4 r0 = *reinterpret_cast<const float4 *>(p.resid + orow * CH + c0);
+                        const float4 r1 = *reinterpret_cast<const float4 *>(p.resid + orow * CH + c0 + 4);
+                        v[0] = r0.x + v[0]; v[1] = r0.y + v[1]; v[2] = r0.z + v[2]; v[3] = r0.w + v[3];
+                        v[4] = r1.x + v[4]; v[5] = r1.y + v[5]; v[6] = r1.z + v[6]; v[7] = r1.w + v[7];
+                    } else if (p.rh) {   // the same, y kept as hi + lo planes (exact to 2^-22; read before the in-place store)
+                        const half8 h8 = *reinterpret_cast<const half8 *>(p.rh + po);
+                        const half8 l8 = *reinterpret_cast<const half8 *>(p.rl + po);
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = ((float)h8[e] + (float)l8[e]) + v[e];
                     }
                     if (p.mod_w) {   // modulate: x * (w + 1) + b   (:197-200)
-                        const float4 mw = *reinterpret_cast<const float4 *>(p.mod_w + c0);
-                        const float4 mb = *reinterpret_cast<const float4 *>(p.mod_b + c0);
-                        v[0] = v[0] * (mw.x + 1.f) + mb.x; v[1] = v[1] * (mw.y + 1.f) + mb.y;
-                        v[2] = v[2] * (mw.z + 1.f) + mb.z; v[3] = v[3] * (mw.w + 1.f) + mb.w;
-                    }
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] = vmax(v[e], 0.2f * v[e]);   // LeakyReLU(0.2)
-                    if (p.proj_w) {   // conv4 (256 -> 3, 1x1): this lane's 4 channels of its pixel
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            const float4 w = *reinterpret_cast<const float4 *>(p.proj_w + c * CH + c0);
-                            pj[c] += w.x * v[0] + w.y * v[1] + w.z * v[2] + w.w * v[3];
+                        for (int e4 = 0; e4 < 2; e4++) {
+                            const float4 mw = *reinterpret_cast<const float4 *>(p.mod_w + c0 + 4 * e4);
+                            const float4 mb = *reinterpret_cast<const float4 *>(p.mod_b + c0 + 4 * e4);
+                            v[4 * e4] = v[4 * e4] * (mw.x + 1.f) + mb.x; v[4 * e4 + 1] = v[4 * e4 + 1] * (mw.y + 1.f) + mb.y;
+                            v[4 * e4 + 2] = v[4 * e4 + 2] * (mw.z + 1.f) + mb.z; v[4 * e4 + 3] = v[4 * e4 + 3] * (mw.w + 1.f) + mb.w;
                         }
                     }
-                    if (p.of32) *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) v[e] = vmax(v[e], 0.2f * v[e]);   // LeakyReLU(0.2)
+                    if (p.proj_w) {   // conv4 (256 -> 3, 1x1): this lane's 8 channels of its pixel
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const float4 w0 = *reinterpret_cast<const float4 *>(p.proj_w + c * CH + c0);
+                            const float4 w1 = *reinterpret_cast<const float4 *>(p.proj_w + c * CH + c0 + 4);
+                            pj[c] += w0.x * v[0] + w0.y * v[1] + w0.z * v[2] + w0.w * v[3] + w1.x * v[4] + w1.y * v[5] + w1.z * v[6] + w1.w * v[7];
+                        }
+                    }
+                    if (p.of32) {
+                        *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
                     if (p.oh) {
-                        const fp16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]), h1 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                        const fp16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h0[0], v[1] - (float)h0[1]);
-                        const fp16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h1[0], v[3] - (float)h1[1]);
-                        half4 hv, lv;
-                        hv[0] = (_Float16)h0[0]; hv[1] = (_Float16)h0[1]; hv[2] = (_Float16)h1[0]; hv[3] = (_Float16)h1[1];
-                        lv[0] = (_Float16)l0[0]; lv[1] = (_Float16)l0[1]; lv[2] = (_Float16)l1[0]; lv[3] = (_Float16)l1[1];
-                        const long po = ((long)(c0 >> 4) * ((long)p.Hb * p.Wb) + ppix) * 16 + (c0 & 15);
-                        *reinterpret_cast<half4 *>(p.oh + po) = hv;
-                        *reinterpret_cast<half4 *>(p.ol + po) = lv;
+                        half8 hv, lv;
+#pragma unroll
+                        for (int e = 0; e < 8; e += 2) {
+                            const fp16x2 hp = __builtin_amdgcn_cvt_pkrtz(v[e], v[e + 1]);
+                            const fp16x2 lp = __builtin_amdgcn_cvt_pkrtz(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
+                            hv[e] = (_Float16)hp[0]; hv[e + 1] = (_Float16)hp[1];
+                            lv[e] = (_Float16)lp[0]; lv[e + 1] = (_Float16)lp[1];
+                        }
+                        *reinterpret_cast<half8 *>(p.oh + po) = hv;
+                        *reinterpret_cast<half8 *>(p.ol + po) = lv;
                     }
                 }
             }
@@ -341,7 +357,10 @@ __global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict_
     const int ib = (int)((g / 64) % 8);
     const int t = (int)(g / (64 * 8));
     const int s = t / taps, tap = t - taps * s;   // same k order as issue_slot
-    const int co = 32 * ib + (lane & 31), h = lane >> 5;
+    // MFMA row i of a 32-row block carries channel 16*((i>>2)&1) + 4*(i>>3) + (i&3) of the block: the C/D register
+    // layout (row = (r&3) + 8*(r>>2) + 4*h) then gives lane half h the 16 CONSECUTIVE channels 16*h + r (epilogue)
+    const int i32 = lane & 31, h = lane >> 5;
+    const int co = 32 * ib + 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3);
     half8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
