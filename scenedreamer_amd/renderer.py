@@ -287,7 +287,8 @@ class Renderer:
             own1 = (row1 - row0 + (self.pad if row1 == H else 0)) * Wp
             sky_sum = sky_c[:own1].sum(dim=0, dtype=torch.float64)
         return dict(vid=vid, d2=d2, rd=rd, sky_c=sky_c, sky_sum=sky_sum, sky_cnt=own1, rows=(p1 - p0), Wp=Wp,
-                    cam_ori=torch.as_tensor(cam_ori, dtype=torch.float32).to(self.dev), mode=mode)
+                    cam_ori=(torch.as_tensor(cam_ori, dtype=torch.float32) if mode == "fused"
+                             else torch.as_tensor(cam_ori, dtype=torch.float32).to(self.dev)), mode=mode)
 
     def band_finish(self, hd, sky_avg, num_samples, cnn_mode=None):
         """Field + CNN for a prepared band given the frame-wide sky_avg [1,64]; returns image rows [1,3,row1-row0,W]."""
@@ -337,7 +338,11 @@ class Renderer:
             vid = vid.view(R, self.M)
             d2 = d2.view(2, R, self.M)
             rd = rd.view(R, 3)
-            cam_ori = torch.as_tensor(pose[0], dtype=torch.float32).to(self.dev)
+            # host value for the fused path (its C entry points take host floats): a device copy here and the .cpu() that
+            # would undo it are two host<->device synchronisations per frame, each draining the launch queue
+            cam_ori = torch.as_tensor(pose[0], dtype=torch.float32)
+            if mode != "fused":
+                cam_ori = cam_ori.to(self.dev)
             if mode == "fused":
                 from . import fused
                 sky_c, sky_avg = fused.sky_fused(self, rd)
