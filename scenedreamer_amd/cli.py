@@ -3,6 +3,7 @@
 
     python -m scenedreamer_amd.cli --output_dir out --seed 8888 [--checkpoint scenedreamer_released.pt]
         [--camera_mode 4 --cam_maxstep 40 --resolution_hw 540 960 --num_samples 40 --cam_ang 72 --scene_size 2048]
+        [--scene world.npz]     # a saved reference world: voxel_t, heightmap, current_height_map, current_semantic_map, trans_mat
     python -m torch.distributed.run --nproc-per-node N ... -m scenedreamer_amd.cli ...     # frames sharded over GPUs
 
 Without --checkpoint (none is available offline) a seeded synthetic scene and random-init weights of the reference's
@@ -25,6 +26,7 @@ def main():
     ap.add_argument("--num_samples", type=int, default=40)
     ap.add_argument("--cam_ang", type=float, default=72)
     ap.add_argument("--scene_size", type=int, default=2048)
+    ap.add_argument("--scene", default="", help="npz with the fields of the reference's voxel handle (pcg_gen.py:161-174)")
     ap.add_argument("--mode", default="fused", choices=["fused", "unfused"])
     args = ap.parse_args()
 
@@ -41,7 +43,17 @@ def main():
 
     scene = weights = style = None
     if rank == 0:
-        scene = synth.make_scene(args.scene_size, 3407, device=dev)
+        if args.scene:
+            z = np.load(args.scene)
+            scene = synth.Scene()
+            scene.voxel_t = torch.from_numpy(z["voxel_t"].astype(np.int32)).to(dev)
+            scene.heightmap = torch.from_numpy(z["heightmap"])
+            scene.current_height_map = torch.from_numpy(z["current_height_map"].astype(np.float32)).to(dev)
+            scene.current_semantic_map = torch.from_numpy(z["current_semantic_map"].astype(np.float32)).to(dev)
+            scene.trans_mat = torch.from_numpy(z["trans_mat"].astype(np.float32))
+            scene.sample_size = int(scene.voxel_t.shape[1])
+        else:
+            scene = synth.make_scene(args.scene_size, 3407, device=dev)
         if args.checkpoint:
             ck = torch.load(args.checkpoint, map_location="cpu")      # inference.py:57-61 ("module." prefix)
             weights = {k[len("module."):] if k.startswith("module.") else k: v for k, v in ck["net_G"].items()}
@@ -57,9 +69,14 @@ def main():
     writer = FrameWriter(out)
     if rank == 0:
         np.save(os.path.join(out, "style.npy"), np.asarray(style))    # scenedreamer.py:564
-    for f in sdist.shard_frames(range(len(poses)), rank, world):
+    mine = sdist.shard_frames(range(len(poses)), rank, world)
+    hw = tuple(args.resolution_hw)
+    if args.mode == "fused":     # next frame's ray casting on a second stream beside the current frame
+        frames = R.render_frames([poses[f] for f in mine], hw, args.num_samples, mode="fused")
+    else:
+        frames = (R.render_frame(poses[f], hw, args.num_samples, mode=args.mode) for f in mine)
+    for f, img in zip(mine, frames):
         print(f"[rank {rank}] Rendering frame {f}", flush=True)
-        img = R.render_frame(poses[f], tuple(args.resolution_hw), args.num_samples, mode=args.mode)
         writer.submit(img, f)
     writer.close()
     if world > 1:
