@@ -901,6 +901,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
     r.next_in_pass = DMA_AHEAD;
 
+    unsigned long long t_stage = 0, t_kernel0 = 0;
+    unsigned n_pass = 0;
+    if constexpr (DBG & 128) t_kernel0 = __builtin_readcyclecounter();
     const int n_groups = (p.n_tiles + 3) >> 2;
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int tile = grp * 4 + wave;
@@ -928,6 +931,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             half8 bh[16], bl[16];
             f32x16 acc[8];
             const float *fin = p.feat + (tc * 8 * 64 + lane) * 8;
+            unsigned long long t_in0 = 0;
+            if constexpr (DBG & 128) t_in0 = __builtin_readcyclecounter();
             const int lab = p.label[tc * 32 + j];
             const float dist = tile_ok ? p.dist[tc * 32 + j] : 0.f;
 #pragma unroll
@@ -936,6 +941,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 const float4 b = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8 + 4);
                 const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 split8(v, bh[s], bl[s]);
+            }
+            if constexpr (DBG & 128) {
+                asm volatile("s_waitcnt vmcnt(0)" ::"v"(bh[7]), "v"(bl[7]) : "memory");
+                t_stage += __builtin_readcyclecounter() - t_in0;
+                n_pass++;
             }
             float part = 0.f;
             const float *wsig = cst + C_WSIGMA;
@@ -1015,6 +1025,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     // the ring runs DMA_AHEAD slots ahead of the last pass: let it land before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    if constexpr (DBG & 128) {   // timing experiment: (input-staging cycles, total cycles, passes) of this wave into net_out
+        if (lane == 0) {
+            float *o = p.net_out + (size_t)(blockIdx.x * 4 + wave) * OUTC;
+            o[0] = (float)t_stage; o[1] = (float)(__builtin_readcyclecounter() - t_kernel0); o[2] = (float)n_pass;
+        }
+    }
 }
 
 // =====================================================================================================
@@ -1354,6 +1370,7 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     switch (dbg) {
 #ifdef SDN_MLP_ABLATION
         case 1: hipLaunchKernelGGL(mlp_kernel<1>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring DMA
+        case 128: hipLaunchKernelGGL(mlp_kernel<128>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // input-staging timer
         case 2: hipLaunchKernelGGL(mlp_kernel<2>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring barrier
         case 3: hipLaunchKernelGGL(mlp_kernel<3>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
         case 4: hipLaunchKernelGGL(mlp_kernel<4>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no activation VALU
