@@ -901,6 +901,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
     r.next_in_pass = DMA_AHEAD;
 
+    // Input prefetch: the next pass's 16 KiB of features (+ label, dist) are loaded into otherwise idle AGPRs while the
+    // output layer of the current pass runs, so the HBM latency of the pass-start loads (3.5 % of a pass) is hidden.
+    // The loads are inline asm (the compiler would place its own, draining waits) and are consumed only through
+    // v_accvgpr_read asm behind a hand-counted wait: after them the output layer always issues its 4 slots x 4 ring
+    // DMAs, so "vmcnt(16)" at the next pass start means the prefetch has landed (more vm operations in between -- the
+    // stores at a group's end -- only make the wait stricter).
+    // The landing registers are the PHYSICAL AGPRs a[190:255], named in the asm text: as C++ values they would be
+    // loop-carried, and hipcc keeps loop-carried values in VGPRs, i.e. copies them out of the AGPRs right behind the
+    // load -- before the data has landed.  The kernel's own allocation stays below a190 (tools/check_lds_hazards.py
+    // verifies that no other instruction touches a[190:255]).
+    long pf_tc = -1;            // pass whose inputs sit in a[190:255] (wave-uniform), -1: none
     unsigned long long t_stage = 0, t_kernel0 = 0;
     unsigned n_pass = 0;
     if constexpr (DBG & 128) t_kernel0 = __builtin_readcyclecounter();
@@ -908,6 +919,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const int tile = grp * 4 + wave;
         const bool tile_ok = tile < p.n_tiles;
+        const int tile_s = grp * 4 + r.wave;              // the same as scalars (r.wave went through readfirstlane)
+        const bool tile_ok_s = tile_s < p.n_tiles;
         const int ray = tile * RAYS_PER_TILE + (j >> 2);
         const bool ray_ok = tile_ok && ray < p.R;
         const uint8_t flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
@@ -933,15 +946,58 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             const float *fin = p.feat + (tc * 8 * 64 + lane) * 8;
             unsigned long long t_in0 = 0;
             if constexpr (DBG & 128) t_in0 = __builtin_readcyclecounter();
-            const int lab = p.label[tc * 32 + j];
-            const float dist = tile_ok ? p.dist[tc * 32 + j] : 0.f;
+            const long tc_s = (long)(tile_ok_s ? tile_s : 0) * p.nch + ch;    // tc as a scalar
+            int lab;
+            float dist;
+            float raw[8][8];
+            if (pf_tc == tc_s && !(DBG & 256)) {
+                if constexpr (DBG & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#define SDN_PF_READ8(S, A0, A1, A2, A3, A4, A5, A6, A7) \
+    asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2 \
+                 "\n\tv_accvgpr_read_b32 %3, a" #A3 "\n\tv_accvgpr_read_b32 %4, a" #A4 "\n\tv_accvgpr_read_b32 %5, a" #A5 \
+                 "\n\tv_accvgpr_read_b32 %6, a" #A6 "\n\tv_accvgpr_read_b32 %7, a" #A7 \
+                 : "=v"(raw[S][0]), "=v"(raw[S][1]), "=v"(raw[S][2]), "=v"(raw[S][3]), "=v"(raw[S][4]), "=v"(raw[S][5]), \
+                   "=v"(raw[S][6]), "=v"(raw[S][7]))
+                SDN_PF_READ8(0, 190, 191, 192, 193, 194, 195, 196, 197);
+                SDN_PF_READ8(1, 198, 199, 200, 201, 202, 203, 204, 205);
+                SDN_PF_READ8(2, 206, 207, 208, 209, 210, 211, 212, 213);
+                SDN_PF_READ8(3, 214, 215, 216, 217, 218, 219, 220, 221);
+                SDN_PF_READ8(4, 222, 223, 224, 225, 226, 227, 228, 229);
+                SDN_PF_READ8(5, 230, 231, 232, 233, 234, 235, 236, 237);
+                SDN_PF_READ8(6, 238, 239, 240, 241, 242, 243, 244, 245);
+                SDN_PF_READ8(7, 246, 247, 248, 249, 250, 251, 252, 253);
+#undef SDN_PF_READ8
+                asm volatile("v_accvgpr_read_b32 %0, a254\n\tv_accvgpr_read_b32 %1, a255" : "=v"(lab), "=v"(dist));
+                if (!tile_ok) dist = 0.f;
+            } else {
+                // first pass of the kernel / after a skipped group: load here.  Inline asm as well, so that hipcc's wait
+                // insertion sees no vector-memory loads at all in this loop (with ordinary loads on this path it puts
+                // vmcnt(0) in front of the AGPR reads of the other path: a full drain of the weight ring per pass)
+                f32x4 t[16];
+                const char *base = reinterpret_cast<const char *>(fin);
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const float4 a = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8);
-                const float4 b = *reinterpret_cast<const float4 *>(fin + (size_t)s * 64 * 8 + 4);
-                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                split8(v, bh[s], bl[s]);
+                for (int k = 0; k < 4; k++) {
+                    const char *a = base + k * 4096;
+                    asm volatile("global_load_dwordx4 %0, %4, off\n\tglobal_load_dwordx4 %1, %4, off offset:16\n\t"
+                                 "global_load_dwordx4 %2, %4, off offset:2048\n\tglobal_load_dwordx4 %3, %4, off offset:2064"
+                                 : "=&v"(t[4 * k]), "=&v"(t[4 * k + 1]), "=&v"(t[4 * k + 2]), "=&v"(t[4 * k + 3]) : "v"(a) : "memory");
+                }
+                asm volatile("global_load_ubyte %0, %2, off\n\tglobal_load_dword %1, %3, off"
+                             : "=&v"(lab), "=&v"(dist) : "v"(p.label + tc * 32 + j), "v"(p.dist + tc * 32 + j) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]),
+                               "+v"(t[8]), "+v"(t[9]), "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15]),
+                               "+v"(lab), "+v"(dist)
+                             :: "memory");
+                if (!tile_ok) dist = 0.f;
+#pragma unroll
+                for (int s = 0; s < 8; s++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) raw[s][e] = t[2 * s + (e >> 2)][e & 3];
             }
+#pragma unroll
+            for (int s = 0; s < 8; s++) split8(raw[s], bh[s], bl[s]);
             if constexpr (DBG & 128) {
                 asm volatile("s_waitcnt vmcnt(0)" ::"v"(bh[7]), "v"(bl[7]) : "memory");
                 t_stage += __builtin_readcyclecounter() - t_in0;
@@ -968,6 +1024,35 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
             }
             // ---- fc_out_c ------------------------------------------------------------------------------------------
+            {   // inputs of the next pass of this wave: the next step of this tile, or the first step of its next group
+                long tn = tc_s + 1;
+                bool has_next = tile_ok_s;
+                if (ch + 1 == p.nch) {
+                    const int tile2 = (grp + (int)gridDim.x) * 4 + r.wave;
+                    has_next = tile2 < p.n_tiles;
+                    tn = (long)tile2 * p.nch;
+                }
+                pf_tc = -1;
+                if (has_next && !(DBG & 256)) {
+                    pf_tc = tn;
+                    const char *base = reinterpret_cast<const char *>(p.feat + ((size_t)tn * 8 * 64 + lane) * 8);
+                    // k-steps 2k, 2k+1 (2048 B apart), two 16-B halves each -> a[190+16k : 205+16k]
+#define SDN_PF_LOAD4(K, R0, R1, R2, R3) \
+    asm volatile("global_load_dwordx4 a[" #R0 ":" #R0 "+3], %0, off\n\tglobal_load_dwordx4 a[" #R1 ":" #R1 "+3], %0, off offset:16\n\t" \
+                 "global_load_dwordx4 a[" #R2 ":" #R2 "+3], %0, off offset:2048\n\tglobal_load_dwordx4 a[" #R3 ":" #R3 "+3], %0, off offset:2064" \
+                 ::"v"(base + (K) * 4096) : "memory", SDN_PF_CLOBBERS)
+                    // (the clobber list is what makes the kernel's register count include a[190:255])
+#define SDN_PF_CLOBBERS "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253"
+                    SDN_PF_LOAD4(0, 190, 194, 198, 202);
+                    SDN_PF_LOAD4(1, 206, 210, 214, 218);
+                    SDN_PF_LOAD4(2, 222, 226, 230, 234);
+                    SDN_PF_LOAD4(3, 238, 242, 246, 250);
+#undef SDN_PF_CLOBBERS
+#undef SDN_PF_LOAD4
+                    asm volatile("global_load_ubyte a254, %0, off" ::"v"(p.label + (size_t)tn * 32 + j) : "memory", "a254");
+                    asm volatile("global_load_dword a255, %0, off" ::"v"(p.dist + (size_t)tn * 32 + j) : "memory", "a255");
+                }
+            }
             f32x16 col[2];
             col[0] = bias_block<0>(cst + C_BC, h);
             col[1] = bias_block<1>(cst + C_BC, h);
@@ -1370,6 +1455,8 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     switch (dbg) {
 #ifdef SDN_MLP_ABLATION
         case 1: hipLaunchKernelGGL(mlp_kernel<1>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring DMA
+        case 256: hipLaunchKernelGGL(mlp_kernel<256>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // no input prefetch
+        case 384: hipLaunchKernelGGL(mlp_kernel<384>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
         case 128: hipLaunchKernelGGL(mlp_kernel<128>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // input-staging timer
         case 2: hipLaunchKernelGGL(mlp_kernel<2>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring barrier
         case 3: hipLaunchKernelGGL(mlp_kernel<3>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;

@@ -71,6 +71,28 @@ def check_kernel(name, lines):
     return n_reads, problems
 
 
+def check_prefetch_agprs(lines, lo=190, hi=255):
+    """mlp_kernel's input prefetch lands in the physical AGPRs a[lo:hi] named in asm text: nothing but those loads and the
+    consuming v_accvgpr_read may touch them, and every read must sit behind a vector-memory wait in the same block."""
+    pf = set(range(lo, hi + 1))
+    n, problems = 0, []
+    for ln, raw in lines:
+        t = raw.split(";")[0].strip()
+        if not t or t.startswith(".") or t.endswith(":"):
+            continue
+        regs = set()
+        for m in re.finditer(r"\ba\[(\d+):(\d+)(\+3)?\]|\ba(\d+)\b", t):
+            if m.group(1):
+                regs.update(range(int(m.group(1)), int(m.group(2)) + 1 + (3 if m.group(3) else 0)))
+            else:
+                regs.add(int(m.group(4)))
+        if regs & pf:
+            n += 1
+            if not (t.startswith("global_load") or t.startswith("v_accvgpr_read_b32")):
+                problems.append((ln, t, "prefetch AGPR touched by a foreign instruction"))
+    return n, problems
+
+
 def main():
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bad = 0
@@ -87,8 +109,13 @@ def main():
                 if start is None:
                     continue
                 end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
-                n, problems = check_kernel(k, list(enumerate(text[start:end], start + 1)))
+                body = list(enumerate(text[start:end], start + 1))
+                n, problems = check_kernel(k, body)
                 print(f"{src}:{k}: {n} LDS reads replayed, {len(problems)} hazard(s)")
+                if k.startswith("mlp_kernel"):
+                    n2, p2 = check_prefetch_agprs(body)
+                    print(f"{src}:{k}: {n2} instructions on the prefetch AGPRs a[190:255], {len(p2)} foreign")
+                    problems = problems + p2
                 for ln, raw, why in problems[:10]:
                     print(f"    line {ln}: {why}: {raw}")
                 bad += len(problems)
