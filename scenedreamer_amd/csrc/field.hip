@@ -467,6 +467,7 @@ struct Ring {
     int lane;
     int voff;             // per-lane byte offset of this wave's first piece inside a slot: wave*4096 + lane*16
     unsigned lds_lane;    // LDS byte address of this lane's 16 B inside fragment 0 of ring position 0
+    int pend_global, pend_in_pass;   // slot whose refill was granted by the last ring_acquire (issued piecewise after it)
 };
 
 __device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_global, int slot_in_pass) {
@@ -482,12 +483,24 @@ __device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_gl
     __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 3072, 0);
 }
 
-// make slot r.g (and r.g+1) readable for everybody, free slot r.g-1 and refill it
+// One of the 4 DMA pieces of the refill granted by the last ring_acquire.  They are issued one behind each of the next
+// unit's first four MFMAs: a global_load_lds costs the issuing wave ~16 cycles of address processing, which fits in
+// the shadow of a 32-cycle MFMA but was dead matrix time when all four followed the barrier back to back.
+template <int K>
+__device__ __forceinline__ void ring_issue_piece(char *lds, const Ring &r) {
+    const int pos = r.pend_global & (NSLOT - 1);
+    const char *sbase = r.wbytes + (size_t)r.pend_in_pass * SLOT_BYTES;
+    char *dbase = lds + LDS_RING + pos * SLOT_BYTES + r.wave * 4096;
+    __builtin_amdgcn_global_load_lds((glb_char *)(sbase + r.voff), (lds_char *)dbase, 16, K * 1024, 0);
+}
+
+// make slot r.g (and r.g+1) readable for everybody, free slot r.g-1 for its refill (ring_issue_piece<0..3>)
 template <int DBG>
 __device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_AHEAD - 2) * 4) : "memory");
     if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
-    if constexpr (!(DBG & 1)) ring_issue(lds, r, r.g + DMA_AHEAD, r.next_in_pass);
+    r.pend_global = r.g + DMA_AHEAD;
+    r.pend_in_pass = r.next_in_pass;
     r.next_in_pass = r.next_in_pass + 1 == r.slots_per_pass ? 0 : r.next_in_pass + 1;
     const int pos = r.g & (NSLOT - 1);
     r.g++;
@@ -757,6 +770,7 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     lds_wait<PF_PREV ? 4 : 0>();
     layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
+    if constexpr (U % UPS == 0 && K < 4 && !(DBG & 1)) ring_issue_piece<(K) & 3>(lds, r); \
     if constexpr (ACT) act_stage<T, HS, SIG, K>(acc, in, bh, bl, part, g); \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
@@ -841,6 +855,7 @@ __device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8
     lds_wait<PF_PREV ? 4 : 0>();
     out_fetch<DBG, U + 1>(bias_pend, h, st);
 #define SDN_STAGE(K) \
+    if constexpr (U % UPS == 0 && K < 4 && !(DBG & 1)) ring_issue_piece<(K) & 3>(lds, r); \
     if constexpr (ACT) { act_stage<T, 0, false, K>(acc, in0, bh, bl, part, g0); act_stage<T, 1, false, K>(acc, in1, bh, bl, part, g1); } \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
