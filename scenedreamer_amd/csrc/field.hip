@@ -730,8 +730,12 @@ struct ActPlan {
     // is first needed at unit 16+2k), or this layer's upper half (fragments 0..NS/2-1) during the last NS/2 k-steps
     // of the lower half
     static constexpr bool PEND = IN_RANGE && HAS_PEND && U < 16 && !(DBG & 4);
-    static constexpr bool OWN = IN_RANGE && HALF == 1 && S >= NS / 2 && !(DBG & 4);
-    static constexpr int M = U - 3 * NS;
+    // own: fragment T may be overwritten once k-step T has been consumed by both row blocks of this half, i.e. from
+    // k-step T+1 on.  NS == 16: fragments 0..7 during k-steps 8..15; NS < 16 (first layers): fragments 0..NS-2 during
+    // k-steps 1..NS-1 (the last upper-half fragments are activated after the layer, un-hidden)
+    static constexpr int S0 = NS == 16 ? 8 : 1;
+    static constexpr bool OWN = IN_RANGE && HALF == 1 && S >= S0 && !(DBG & 4);
+    static constexpr int M = U - 2 * NS - 2 * S0;
     static constexpr int T = PEND ? 8 + U / 2 : (OWN ? M / 2 : 0);
     static constexpr int HS = PEND ? U % 2 : (OWN ? M % 2 : 0);
     static constexpr bool SIG = PEND ? SIG_PEND : SIG_OWN;
@@ -1020,14 +1024,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             }
             float part = 0.f;
             const float *wsig = cst + C_WSIGMA;
-            // ---- fc_1: 8 k-steps; its upper half is activated into fragments 0..3 behind its own tail, the rest of
-            //      the upper half (fragments 4..7) right after it, its lower half behind fc_2's head ------------------
+            // ---- fc_1: 8 k-steps; fragments 0..6 of its upper half are activated behind its own lower half, fragment 7
+            //      right after it, its lower half behind fc_2's head ---------------------------------------------------
             const float *bias1 = cst + C_LABEL_BIAS + lab * HID;
             layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, bias1, bias1, wsig, h, part);
-            act_step<4, false>(acc, bias1, wsig, h, bh, bl, part);
-            act_step<5, false>(acc, bias1, wsig, h, bh, bl, part);
-            act_step<6, false>(acc, bias1, wsig, h, bh, bl, part);
-            act_step<7, false>(acc, bias1, wsig, h, bh, bl, part);
+            act_step<7, false>(acc, bias1, wsig, h, bh, bl, part);   // fragments 0..6 were activated inside the layer
             // ---- fc_2 .. fc_6.  fc_4 (l == 2) feeds the density head (layers.py:114): its upper half is activated
             //      inside l == 2, its lower half as the pending work of l == 3 ----------------------------------------
 #pragma unroll 1
@@ -1254,11 +1255,10 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
         }
         float part = 0.f;
         const float *nul = cst;
-        // fc1 (+ style term): 4 k-steps; fragments 0,1 of its upper half are activated behind its own tail, the
-        // remaining six (2..7) right after, the lower half behind fc2's head
+        // fc1 (+ style term): 4 k-steps; fragments 0..2 of its upper half are activated behind its own lower half, the
+        // remaining five (3..7) right after, the lower half behind fc2's head
         layer8<DBG, 4, false, false, false>(lds, r, bh, bl, acc, cst + SC_BIAS1, cst + SC_BIAS1, nul, h, part);
-        act_step<2, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
-        act_step<3, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<3, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);   // fragments 0..2 were activated inside the layer
         act_step<4, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
         act_step<5, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
         act_step<6, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
