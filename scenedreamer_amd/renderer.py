@@ -63,6 +63,8 @@ class Renderer:
     def set_scene(self, scene):
         self.scene = scene
         self.voxel_t = scene.voxel_t.to(self.dev)
+        if self.voxel_t.is_cuda:
+            ops.voxel_occupancy(self.voxel_t)   # built here, on the caller's stream, before any side-stream ray casting
         w = self.w
         with torch.no_grad():  # ConditionalHashGrid.forward, layers.py:40-55
             h = _lrelu(F.conv2d(scene.current_height_map.to(self.dev), w["world_encoder.hconv_head.weight"],
