@@ -121,6 +121,37 @@ def test_library_exports_every_declared_symbol():
     assert lib.sdn_abi_version() == 1
 
 
+def _header_prototypes():
+    """name -> list of C parameter declarations, parsed from include/sdnative.h."""
+    txt = open(os.path.join(ROOT, "include", "sdnative.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    protos = {}
+    for m in re.finditer(r"\b(sdn_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+        args = " ".join(m.group(2).split())
+        protos[m.group(1)] = [] if args in ("", "void") else [a.strip() for a in args.split(",")]
+    return protos
+
+
+def test_ctypes_signatures_match_the_header():
+    """The ctypes binding (capi.py) and include/sdnative.h must agree on every entry point: parameter count, and
+    pointer / integer / float class of each parameter (an ABI drift would otherwise only show up as garbage on the GPU)."""
+    from scenedreamer_amd import capi
+    protos = _header_prototypes()
+    sigs = dict(capi._SIGNATURES)
+    sigs.update(capi.EXTRA_SIGNATURES)
+    assert set(sigs) == set(protos), sorted(set(sigs) ^ set(protos))
+    for name, (_, argtypes) in sigs.items():
+        decl = protos[name]
+        assert len(decl) == len(argtypes), f"{name}: header has {len(decl)} parameters, ctypes {len(argtypes)}"
+        for d, t in zip(decl, argtypes):
+            is_ptr_c = "*" in d or "sdn_stream_t" in d
+            is_float_c = (not is_ptr_c) and re.search(r"\bfloat\b|\bdouble\b", d) is not None
+            is_ptr_py = t is ctypes.c_void_p
+            is_float_py = t in (ctypes.c_float, ctypes.c_double)
+            assert is_ptr_c == is_ptr_py and is_float_c == is_float_py, f"{name}: `{d}` bound as {t.__name__}"
+
+
 def test_argument_validation_without_a_gpu():
     """Unsupported shapes are rejected before any launch, with the reference's error text."""
     from scenedreamer_amd import capi
