@@ -399,10 +399,12 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
 //
 //  * weights: the 4 waves of a workgroup share ONE copy of the packed weight stream (1.47 MB per pass, identical
 //    for every pass).  It flows L2 -> LDS by LDS-DMA (global_load_lds, 16 B/lane, no VGPRs) into a ring of
-//    8 slots x 16 KiB (= 4 units); every wave issues 4 of a slot's 16 1-KiB pieces, 7 slots ahead of use.
-//    Per slot: counted s_waitcnt vmcnt(20) (this wave's pieces of slots g and g+1 have landed) -> raw s_barrier
-//    (everybody's have, and everybody is done with slot g-1) -> DMA for slot g+7 into the position of slot g-1.
-//    Fragments go LDS -> registers by ds_read_b128 (lane-linear image: conflict-free) through a 4-unit register
+//    4 slots x 32 KiB (= 8 units = 48 MFMAs per wave); every wave issues 8 of a slot's 32 1-KiB pieces, 3 slots
+//    ahead of use, one piece behind each of the first MFMAs after the slot's barrier.
+//    Per slot: counted s_waitcnt vmcnt(8) (this wave's pieces of slots g and g+1 have landed) -> raw s_barrier
+//    (everybody's have, and everybody is done with slot g-1) -> DMA for slot g+3 into the position of slot g-1.
+//    (8 x 16 KiB slots, 7 ahead, measured 0.9 % slower on the same box: twice the barriers.)
+//    Fragments go LDS -> registers by ds_read_b128 (lane-linear image: conflict-free) through a 3-unit register
 //    ring that runs across slot boundaries.  LDS read traffic 85 B/clk/CU of 256, L2 -> LDS 21 B/clk/CU.
 //    (A first version fetched fragments per wave from L2: 85 B/clk/CU through a 64 B/clk/CU path, 40.8 % MFMA busy.)
 //  * the kernel runs ONE wave per SIMD (the 32 samples x 256 activations as hi+lo f16 and the 32 x 256 f32
@@ -415,10 +417,12 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
 //    the upper half of layer l+1 during its own last k-steps 8-15 of the lower half (k-steps 0-7 of its input are
 //    dead by then, so the new B fragments overwrite them).  No second accumulator set is needed.
 //  * density head, volume rendering, clamp, sky blend: VALU epilogue per pass / per ray tile.
-constexpr int NSLOT = 8;
-constexpr int SLOT_BYTES = 16384;
-constexpr int DMA_AHEAD = 7;
-constexpr int SLOTS_PER_PASS = 8 + 5 * 16 + 4;   // 92
+constexpr int UNITS_PER_SLOT = 8;                  // one barrier per 8 units (48 MFMAs per wave)
+constexpr int NSLOT = 4;
+constexpr int SLOT_BYTES = UNITS_PER_SLOT * 4096;  // 32 KiB
+constexpr int DMA_AHEAD = 3;
+constexpr int PIECES = SLOT_BYTES / 4096;          // 1-KiB DMA pieces per wave and slot (4 waves)
+constexpr int SLOTS_PER_PASS = (8 + 5 * 16 + 4) * 4 / UNITS_PER_SLOT;   // 46
 constexpr int LDS_RING = 0;
 constexpr int LDS_CONST = NSLOT * SLOT_BYTES;     // fp32 constant block
 constexpr int LDS_FLAGS = LDS_CONST + ((C_TOTAL * 4 + 255) / 256) * 256;
@@ -470,17 +474,23 @@ struct Ring {
     int pend_global, pend_in_pass;   // slot whose refill was granted by the last ring_acquire (issued piecewise after it)
 };
 
+template <int K>
+__device__ __forceinline__ void ring_dma(const char *sbase, char *dbase, const Ring &r) {
+    // address = uniform (SGPR) slot base + one per-lane VGPR offset + immediate; LDS destination is wave-uniform;
+    // the instruction offset is added to the global AND to the LDS address (LDS = M0 + offset + lane*16)
+    // (the immediate is a 13-bit signed field: 4096 and up would silently wrap to negative offsets)
+    __builtin_amdgcn_global_load_lds((glb_char *)(sbase + r.voff + (K / 4) * 4096), (lds_char *)(dbase + (K / 4) * 4096), 16,
+                                     (K % 4) * 1024, 0);
+}
+
 __device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_global, int slot_in_pass) {
     const int pos = slot_global & (NSLOT - 1);
-    // address = uniform (SGPR) slot base + one per-lane VGPR offset + immediate; LDS destination is wave-uniform
     const char *sbase = r.wbytes + (size_t)slot_in_pass * SLOT_BYTES;
-    char *dbase = lds + LDS_RING + pos * SLOT_BYTES + r.wave * 4096;
-    // the instruction offset is added to the global AND to the LDS address (LDS = M0 + offset + lane*16)
-    glb_char *src = (glb_char *)(sbase + r.voff);
-    __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 1024, 0);
-    __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 2048, 0);
-    __builtin_amdgcn_global_load_lds(src, (lds_char *)dbase, 16, 3072, 0);
+    char *dbase = lds + LDS_RING + pos * SLOT_BYTES + r.wave * (PIECES * 1024);
+    ring_dma<0>(sbase, dbase, r); ring_dma<1>(sbase, dbase, r); ring_dma<2>(sbase, dbase, r); ring_dma<3>(sbase, dbase, r);
+    if constexpr (PIECES == 8) {
+        ring_dma<4>(sbase, dbase, r); ring_dma<5>(sbase, dbase, r); ring_dma<6>(sbase, dbase, r); ring_dma<7>(sbase, dbase, r);
+    }
 }
 
 // One of the 4 DMA pieces of the refill granted by the last ring_acquire.  They are issued one behind each of the next
@@ -490,14 +500,14 @@ template <int K>
 __device__ __forceinline__ void ring_issue_piece(char *lds, const Ring &r) {
     const int pos = r.pend_global & (NSLOT - 1);
     const char *sbase = r.wbytes + (size_t)r.pend_in_pass * SLOT_BYTES;
-    char *dbase = lds + LDS_RING + pos * SLOT_BYTES + r.wave * 4096;
-    __builtin_amdgcn_global_load_lds((glb_char *)(sbase + r.voff), (lds_char *)dbase, 16, K * 1024, 0);
+    char *dbase = lds + LDS_RING + pos * SLOT_BYTES + r.wave * (PIECES * 1024);
+    ring_dma<K>(sbase, dbase, r);
 }
 
 // make slot r.g (and r.g+1) readable for everybody, free slot r.g-1 for its refill (ring_issue_piece<0..3>)
 template <int DBG>
 __device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_AHEAD - 2) * 4) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DMA_AHEAD - 2) * PIECES) : "memory");
     if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
     r.pend_global = r.g + DMA_AHEAD;
     r.pend_in_pass = r.next_in_pass;
@@ -752,7 +762,7 @@ template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
 __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
                                             f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
                                             int h, float &part) {
-    constexpr int UNITS = NS * 4, RD = RING_DEPTH, UPS = 4;
+    constexpr int UNITS = NS * 4, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
     using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U>;
     if constexpr (U % UPS == 0 && U != 0) {
         st.pos_cur = ring_acquire<DBG>(lds, r);
@@ -774,7 +784,7 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     lds_wait<PF_PREV ? 4 : 0>();
     layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
-    if constexpr (U % UPS == 0 && K < 4 && !(DBG & 1)) ring_issue_piece<(K) & 3>(lds, r); \
+    if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
     if constexpr (ACT) act_stage<T, HS, SIG, K>(acc, in, bh, bl, part, g); \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
@@ -840,7 +850,7 @@ __device__ __forceinline__ void out_fetch(const float *bias_pend, int h, OutStat
 template <int DBG, int U>
 __device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8 (&bh)[16], half8 (&bl)[16],
                                          const f32x16 (&acc)[8], f32x16 (&col)[2], const float *bias_pend, int h, float &part) {
-    constexpr int UNITS = 16, RD = RING_DEPTH, UPS = 4;
+    constexpr int UNITS = 16, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
     if constexpr (U % UPS == 0 && U != 0) {
         st.pos_cur = ring_acquire<DBG>(lds, r);
         st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
@@ -859,7 +869,7 @@ __device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8
     lds_wait<PF_PREV ? 4 : 0>();
     out_fetch<DBG, U + 1>(bias_pend, h, st);
 #define SDN_STAGE(K) \
-    if constexpr (U % UPS == 0 && K < 4 && !(DBG & 1)) ring_issue_piece<(K) & 3>(lds, r); \
+    if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
     if constexpr (ACT) { act_stage<T, 0, false, K>(acc, in0, bh, bl, part, g0); act_stage<T, 1, false, K>(acc, in1, bh, bl, part, g1); } \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
@@ -914,7 +924,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     r.g = 0;
     r.wave = __builtin_amdgcn_readfirstlane(wave);
     r.lane = lane;
-    r.voff = r.wave * 4096 + lane * 16;
+    r.voff = r.wave * (PIECES * 1024) + lane * 16;
     r.lds_lane = (unsigned)(size_t)(const lds_char *)(lds + LDS_RING) + lane * 16;
 #pragma unroll
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
@@ -1143,7 +1153,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
 // bias on the host.  The per-feature sum over rays (for sky_avg) is reduced per wave and written as one row of
 // partial sums per wave (added up by the caller in a fixed order: reproducible, unlike float atomics).
 constexpr int SKY_IN = 33, SKY_K0 = 64;                       // encoded ray direction, padded to 4 k-steps
-constexpr int SKY_SLOTS = 4 + 4 * 16 + 4;                     // 72
+constexpr int SKY_SLOTS = (4 + 4 * 16 + 4) * 4 / UNITS_PER_SLOT;   // 36
 constexpr size_t SKY_L0_FRAGS = 16 * 4 * 64;                  // 16 units
 constexpr size_t SKY_PACKED_FRAGS = SKY_L0_FRAGS + 4 * LH_FRAGS + LO_FRAGS;
 constexpr int SC_BIAS1 = 0;                                   // [256] fc1.bias + fc_z_a(z)
@@ -1229,7 +1239,7 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
     r.g = 0;
     r.wave = __builtin_amdgcn_readfirstlane(wave);
     r.lane = lane;
-    r.voff = r.wave * 4096 + lane * 16;
+    r.voff = r.wave * (PIECES * 1024) + lane * 16;
     r.lds_lane = (unsigned)(size_t)(const lds_char *)(lds + LDS_RING) + lane * 16;
 #pragma unroll
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
