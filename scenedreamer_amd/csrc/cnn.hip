@@ -164,6 +164,7 @@ __device__ __forceinline__ void conv_unit(char *lds, const ConvParams &p, f32x16
         SDN_GAP(0) SDN_GAP(1) SDN_GAP(2) SDN_GAP(3) SDN_GAP(4)
     } else {
         acc[ib] = mfma16(au[0], bcur[0], acc[ib]);
+        __builtin_amdgcn_sched_barrier(0);   // the matrix instruction first: the gap's address arithmetic runs in its shadow
         SDN_GAP(0)
         acc[ib + 1] = mfma16(au[2], bcur[0], acc[ib + 1]);
         SDN_GAP(1)
@@ -230,9 +231,8 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
 #pragma unroll
             for (int par = 0; par < 2; par++) {
                 const int kt = kt2 + par;
-                // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free ---
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
-                if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+                // this k-step's bookkeeping first: it then runs while the wave would wait for the others at the barrier
+                // (behind the barrier it is ~20 scalar instructions of dead matrix time per k-step for every wave)
                 const int qn = kt + AHEAD;   // k-step to fetch during this one, possibly of the next patch
                 const int kt_issue = qn < ksteps ? qn : qn - ksteps;
                 const long boff_issue = qn < ksteps ? boff : boff_n;
@@ -241,6 +241,11 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                 const unsigned slot = lds_lane + pos_use * SLOT_BYTES;
                 pos_use = pos_use + 1 == NSLOT ? 0 : pos_use + 1;
                 const unsigned slot_n = lds_lane + pos_use * SLOT_BYTES;
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free ---
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
+                if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
                 if (!primed) {   // very first k-step of the kernel only
                     ds_read16<0>(b[0][0], slot + b_off);
                     ds_read16<1024>(b[0][1], slot + b_off);
