@@ -152,6 +152,20 @@ def test_ctypes_signatures_match_the_header():
             assert is_ptr_c == is_ptr_py and is_float_c == is_float_py, f"{name}: `{d}` bound as {t.__name__}"
 
 
+def test_hand_counted_waits_have_no_hazards():
+    """tools/check_lds_hazards.py: compile the MFMA kernels to ISA and replay them -- no instruction may touch a register
+    whose inline-asm ds_read has not been waited for, and the MLP's prefetch AGPRs belong to the prefetch alone."""
+    import shutil
+    import subprocess
+    import sys
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lds_hazards.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "mlp_kernel" in r.stdout and "conv_kernel" in r.stdout and " 0 hazard(s)" in r.stdout
+
+
 def test_argument_validation_without_a_gpu():
     """Unsupported shapes are rejected before any launch, with the reference's error text."""
     from scenedreamer_amd import capi
