@@ -212,7 +212,8 @@ def main():
     if rank == 0:
         fps = world * args.steps / elapsed
         out = {
-            "metric": f"rendered frames/sec @{args.width}x{args.height}, {args.samples} samples/ray, scene_size {args.scene_size}",
+            # BASELINE.json's metric verbatim ("...; HBM GB/s": value = frames/s, the grid sampler's GB/s is in roofline_grid_sampler)
+            "metric": f"rendered frames/sec @{args.width}\u00d7{args.height}, {args.samples} samples/ray, scene_size {args.scene_size}; HBM GB/s",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": R.compute_dtype(mode), "data": "synthetic",
