@@ -374,8 +374,11 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
                 }
             }
             float *o = fout + (size_t)s * 64 * 8;
-            *reinterpret_cast<float4 *>(o) = make_float4(res[0], res[1], res[2], res[3]);
-            *reinterpret_cast<float4 *>(o + 4) = make_float4(res[4], res[5], res[6], res[7]);
+            // streaming stores: the 4.9 GB of features are written once and read once by the MLP kernel; they should not
+            // displace the collapsed table (the gathers' working set) from L2 / Infinity Cache
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f4v{res[0], res[1], res[2], res[3]}, reinterpret_cast<f4v *>(o));
+            __builtin_nontemporal_store(f4v{res[4], res[5], res[6], res[7]}, reinterpret_cast<f4v *>(o + 4));
         }
     }
     // per-ray flags: any over the ray's 4 lanes
