@@ -87,7 +87,7 @@ def cpu_baseline(args, weights, scene_cpu_small, budget_s):
     while True:
         FR.render_frame_tiled(weights, lut, vox, p, hw, args.samples, z, genc)
         reps += 1
-        if time.time() - t0 > budget_s or reps >= 3:
+        if time.time() - t0 > budget_s or reps >= 16:      # ~10-30 s of host work (bounded sample)
             break
     dt = (time.time() - t0) / reps
     tile_rays = 158 * 158
