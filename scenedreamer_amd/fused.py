@@ -66,12 +66,12 @@ def prepare_style(R):
     return R._fused_style
 
 
-def _buffers(R, n_rays, ns):
-    key = (n_rays, ns)
+def _buffers(R, n_rays, ns, slot=0):
+    key = (n_rays, ns, slot)
     cache = R.__dict__.setdefault("_fused_buf", {})
     if key not in cache:
         lib = _lib()
-        while len(cache) >= 2:      # e.g. the two apron settings of one resolution; older shapes are dropped
+        while len(cache) >= 4:      # two apron settings x two pipeline slots of one resolution; older shapes are dropped
             cache.pop(next(iter(cache)))
         aux = lib.sdn_field_aux_elems(n_rays, ns)
         cache[key] = dict(
@@ -101,6 +101,23 @@ def encode(R, vid, d2, rd, cam_ori, ns, buf=None):
 
 
 FEATURE_BUFFER_BYTES = 32 << 30   # rays are processed in chunks whose encode -> mlp feature buffer stays below this
+
+
+def mlp_from(R, buf, sky_c, sky_avg, n_rays, ns):
+    """Second half of field_fused for an already encoded ray set (the pipelined trajectory path)."""
+    st = R._fused_style or prepare_style(R)
+    st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
+    net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
+    with torch.cuda.device(R.dev):
+        rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
+                                  buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
+                                  sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, 0, _stream(R.dev))
+    capi.check(rc, "sdn_field_mlp")
+    return net_out
+
+
+def single_chunk(n_rays, ns):
+    return n_rays * (_lib().sdn_field_feat_bytes(32, ns) // 32) <= FEATURE_BUFFER_BYTES
 
 
 def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns):

@@ -394,10 +394,13 @@ class Renderer:
             return img
 
 
-def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="fused", **kw):
-    """Generator over the frames of a trajectory with the ray casting of frame i+1 issued on a second stream while
-    frame i is evaluated: rvip_kernel is latency bound, uses 20 registers and no LDS, so its waves co-reside with the
-    one-workgroup-per-CU MFMA kernels (measured: 1.5 ms of ray casting hidden to ~0.4 ms)."""
+def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="fused", apron="minimal", **kw):
+    """Generator over the frames of a trajectory, software-pipelined over two streams: the front half of frame i+1
+    (ray casting, sky MLP, sample encode) is issued on a second stream while the back half of frame i (field MLP, render
+    CNN) runs.  rvip_kernel (20 registers, no LDS) co-resides with the one-workgroup-per-CU MFMA kernels; the sky and
+    encode kernels fill the CUs that idle at the tails and launch boundaries of the MFMA kernels.  Images are bit-identical
+    to render_frame (tests/test_fullsize_gpu.py)."""
+    from . import fused
     poses = list(poses)
     if not poses:
         return
@@ -405,25 +408,55 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
     side = getattr(self, "_side_stream", None)
     if side is None:
         side = self._side_stream = torch.cuda.Stream(self.dev)
+    f0, c0, cam_res = frame_intrinsics(poses[0][3], resolution_hw, self.pad)
+    crop = self.pad // 2
+    o = crop - CNN_HALO if (apron == "minimal" and crop > CNN_HALO) else 0
+    Hp, Wp = cam_res[0] - 2 * o, cam_res[1] - 2 * o
+    deep = mode == "fused" and not kw and fused.single_chunk(Hp * Wp, num_samples)
 
-    def cast(pose):
+    def front(pose, slot):
         start = torch.cuda.Event()
-        start.record(main)                      # inputs (scene, occupancy grid) are produced on the main stream
+        start.record(main)                      # everything of the frame that used this slot before has been enqueued
         with torch.cuda.stream(side), torch.no_grad():
             side.wait_event(start)
-            out = self.cast_rays(pose, resolution_hw)
+            vid, d2, rd, res = self.cast_rays(pose, resolution_hw)
+            out = (vid, d2, rd, res)
+            if deep:
+                H0, W0 = res
+                sky_c, sky_avg = fused.sky_fused(self, rd.view(H0 * W0, 3))
+                vid = vid.view(H0, W0, self.M)[o:H0 - o, o:W0 - o].reshape(-1, self.M).contiguous()
+                d2 = d2.view(2, H0, W0, self.M)[:, o:H0 - o, o:W0 - o].reshape(2, -1, self.M).contiguous()
+                rdc = rd.view(H0, W0, 3)[o:H0 - o, o:W0 - o].reshape(-1, 3).contiguous()
+                sky_c = sky_c.view(H0, W0, 64)[o:H0 - o, o:W0 - o].reshape(-1, 64).contiguous()
+                buf = fused.encode(self, vid, d2, rdc, torch.as_tensor(pose[0], dtype=torch.float32), num_samples,
+                                   fused._buffers(self, vid.shape[0], num_samples, slot))
+                out = (buf, sky_c, sky_avg, vid.shape[0])
+                keep = (sky_c, sky_avg)
+            else:
+                keep = out[:3]
             done = torch.cuda.Event()
             done.record(side)
-        for t in out[:3]:
+        for t in keep:
             t.record_stream(main)               # allocated on the side stream, consumed on the main stream
         return out, done
 
-    nxt = cast(poses[0])
+    nxt = front(poses[0], 0)
     for i, pose in enumerate(poses):
         cur, done = nxt
-        nxt = cast(poses[i + 1]) if i + 1 < len(poses) else None
+        nxt = front(poses[i + 1], (i + 1) & 1) if i + 1 < len(poses) else None
         main.wait_event(done)
-        yield self.render_frame(pose, resolution_hw, num_samples, mode=mode, _precast=cur, **kw)
+        if not deep:
+            yield self.render_frame(pose, resolution_hw, num_samples, mode=mode, apron=apron, _precast=cur, **kw)
+            continue
+        buf, sky_c, sky_avg, n = cur
+        with torch.no_grad():
+            net_out = fused.mlp_from(self, buf, sky_c, sky_avg, n, num_samples).view(1, Hp, Wp, 64)
+            if getattr(self, "_mfma_cnn", None) is None:
+                from .cnn import MfmaCNN
+                self._mfma_cnn = MfmaCNN(self)
+            img = self._mfma_cnn(net_out)
+            c = crop - o
+            yield img[:, :, c:-c, c:-c] if c else img
 
 
 Renderer.render_frames = _render_frames
