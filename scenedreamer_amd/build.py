@@ -40,7 +40,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256()
-    names = sorted(os.listdir(CSRC)) + ["../../include/sdnative.h", "../build.py"]
+    names = sorted(n for n in os.listdir(CSRC) if n.endswith((".hip", ".h"))) + ["../../include/sdnative.h", "../build.py"]
     for n in names:
         p = os.path.join(CSRC, n)
         if os.path.isfile(p):
