@@ -253,9 +253,14 @@ def render_cnn(w, net_out, z, dtype=torch.float32):
 
 
 def render_frame_tiled(w, lut, vox_np, pose, resolution_hw, num_samples, z, global_enc, pad=30, tile_size=128,
-                       max_blocks=6, dtype=torch.float32):
+                       max_blocks=6, dtype=torch.float32, tiles=None):
     """inference_givenstyle's per-frame body, scenedreamer.py:573-628: ray casting on the padded frame,
-    sky pre-pass, 128-px tiles with a 30-px apron, CNN per tile, crop and stitch.  Returns image [1,3,H,W]."""
+    sky pre-pass, 128-px tiles with a 30-px apron, CNN per tile, crop and stitch.  Returns image [1,3,H,W].
+
+    tiles=[(ih, iw), ...]: evaluate only these tiles of the reference's grid (full-size configurations, where
+    the whole frame costs minutes of CPU) and return {(ih, iw): (row0, col0, image_tile [1,3,h,w])} with
+    row0/col0 the tile's position in the cropped output frame; ray casting and the sky pre-pass still cover
+    the whole padded frame, as in the reference."""
     cam_ori, cam_dir, cam_up, cam_f = pose
     H, W = resolution_hw
     cam_res = [H + pad, W + pad]
@@ -269,16 +274,25 @@ def render_frame_tiled(w, lut, vox_np, pose, resolution_hw, num_samples, z, glob
     nh = (cam_res[0] - pad + tile_size - 1) // tile_size
     nw = (cam_res[1] - pad + tile_size - 1) // tile_size
     rows = []
+    picked = {}
     for ih in range(nh):
         h0, h1 = ih * tile_size, min(ih * tile_size + tile_size + pad, cam_res[0])
         cols = []
         for iw in range(nw):
             w0, w1 = iw * tile_size, min(iw * tile_size + tile_size + pad, cam_res[1])
+            if tiles is not None and (ih, iw) not in tiles:
+                continue
             no = forward_perpix(w, lut, vox_np.shape, vid[:, h0:h1, w0:w1], d2[:, :, h0:h1, w0:w1], rd[:, h0:h1, w0:w1],
                                 cam_ori_t, z, global_enc, num_samples, sky_avg=sky_avg, dtype=dtype)
             img = render_cnn(w, no, z, dtype)
             if pad != 0:
                 img = img[:, :, pad // 2:-pad // 2, pad // 2:-pad // 2]
+            if tiles is not None:
+                picked[(ih, iw)] = (h0, w0, img)
+                continue
             cols.append(img)
-        rows.append(torch.cat(cols, dim=-1))
+        if tiles is None:
+            rows.append(torch.cat(cols, dim=-1))
+    if tiles is not None:
+        return picked
     return torch.cat(rows, dim=-2)

@@ -4,7 +4,8 @@
 
 Runs imaginaire.generators.scenedreamer.Generator (_forward_perpix, _forward_global, style_net,
 world_encoder, sky_net, EvalCameraController) on CPU with the three native ops served by the C
-oracle, on seeded synthetic inputs (scenedreamer_amd/synth.py), and records small input/output
+oracle (`--native ref`: by the reference's own sources compiled for the host, oracle/_ref -- the
+two produce identical files, tests/test_ref_pin_cpu.py), on seeded synthetic inputs (scenedreamer_amd/synth.py), and records small input/output
 vectors.  Also exports the minecraft-id -> reduced-label LUT (data derived from the reference's
 CSV tables) to scenedreamer_amd/data/mc2reduced.json.
 """
@@ -32,7 +33,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    RH.install("oracle")
+    RH.install("ref" if "ref" in sys.argv[1:] else "oracle")
     scene = synth.make_scene(SCENE_S, SCENE_SEED)
     weights = synth.make_weights(W_SEED)
     G, cfg = RH.build_generator(weights, scene)

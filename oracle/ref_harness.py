@@ -23,6 +23,9 @@ def available():
     return os.path.isdir(os.path.join(REFERENCE, "imaginaire"))
 
 
+_installed = None
+
+
 def _stub(name):
     m = types.ModuleType(name)
     m.__dict__["__getattr__"] = lambda attr: (_ for _ in ()).throw(NotImplementedError(f"{name}.{attr} (stub)"))
@@ -33,10 +36,25 @@ def install(native="oracle"):
     """Put the reference on sys.path with the stub / shim modules in place.
 
     native="oracle": voxlib/_gridencoder run the C oracle on CPU tensors.
+    native="ref":    they are the reference's OWN sources compiled for the host (oracle/_ref,
+                     oracle/build_ref.py) -- the whole reference, Python and native, on the CPU.
     native="hip":    they are scenedreamer_amd's HIP-backed shims (needs a GPU).
     """
     sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
     from . import oracle as O
+
+    # modules bound to another backend by an earlier install() (the reference binds `voxlib` / `_gridencoder`
+    # at import time: gancraft/voxlib/__init__.py:7, gridencoder/grid.py:9-12) must be re-imported
+    global _installed
+    if _installed != native:
+        import scenedreamer_amd
+        if scenedreamer_amd.SHIM_DIR in sys.path:
+            sys.path.remove(scenedreamer_amd.SHIM_DIR)
+        for name in list(sys.modules):
+            if name.split(".")[0] in ("imaginaire", "gridencoder", "voxlib", "_gridencoder", "upfirdn2d_cuda",
+                                      "bias_act_cuda"):
+                del sys.modules[name]
+    _installed = native
 
     for name in ("cv2", "imageio", "upfirdn2d_cuda", "bias_act_cuda"):
         if name not in sys.modules:
@@ -45,6 +63,10 @@ def install(native="oracle"):
     if native == "hip":
         import scenedreamer_amd
         scenedreamer_amd.install_shims()
+    elif native == "ref":
+        from . import ref_native
+        sys.modules["voxlib"] = ref_native.load("voxlib")
+        sys.modules["_gridencoder"] = ref_native.load("_gridencoder")
     else:
         vox = types.ModuleType("voxlib")
 
