@@ -12,8 +12,15 @@ shapes (no checkpoint is available offline).  Frames are independent, so ranks s
 with no data-path collective (weak scaling: K frames per rank); RCCL is only used before the timed
 region to broadcast the scene volume / weights / style code from rank 0.
 
-Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` for the dominant
-grid-sample kernel and, at N=1, `cpu_baseline` (the CPU oracle timed on this box's host cores).
+Other BASELINE.json configurations are one command each:
+    --config 3                     1920x1080, 40 samples/ray, one GPU
+    --config 4   (with --gpus 8)   960x540x24, cam_maxstep=256: all 256 frames of the orbit sharded over the ranks
+    --config 5   (with --gpus 8)   3840x2160x40, ONE frame per step rendered tile-parallel (row bands) by all ranks;
+                                   the only exchange is the all_reduce of the frame-wide sky mean ("scaling": "strong")
+(--bench-mode frames|tile-parallel, --cam-maxstep, --height/--width/--samples give the same control by hand.)
+
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` for the dominant kernel (the field MLP),
+`roofline_grid_sampler` and, at N=1, `cpu_baseline` (the CPU oracle timed on this box's host cores).
 """
 import argparse
 import json
@@ -21,11 +28,12 @@ import os
 import sys
 import time
 
-# Host threads for the cpu_baseline leg: both OpenMP runtimes in the process (PyTorch's and the C oracle's)
-# read this at load time.  Capped at 32: on the 256-thread GPU host two runtimes spinning 256 threads each
-# made the oracle 10x SLOWER than on 8 cores.
-CPU_THREADS = int(os.environ.get("SDN_CPU_THREADS", min(os.cpu_count() or 1, 32)))
-os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS))
+# Host threads for the cpu_baseline leg: both OpenMP runtimes in the process (PyTorch's and the C oracle's) read
+# OMP_NUM_THREADS at load time as their MAXIMUM; cpu_baseline() then calibrates the thread count that scales best
+# (on the 256-thread GPU host two runtimes spinning 256 threads each made the oracle 10x SLOWER than 8 cores:
+# passive waiting + a calibrated count instead of "all of them").
+CPU_THREADS_MAX = int(os.environ.get("SDN_CPU_THREADS", min(os.cpu_count() or 1, 128)))
+os.environ.setdefault("OMP_NUM_THREADS", str(CPU_THREADS_MAX))
 os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")   # the per-scene world-encoder convolutions: no exhaustive MIOpen search
@@ -58,49 +66,80 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra loops (other apron setting, delivered rate): for the very large configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget-s", type=float, default=20.0)
-    return ap.parse_args()
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0)
+    ap.add_argument("--cam-maxstep", type=int, default=40, help="poses of the pattern-0 orbit (reference cam_maxstep)")
+    ap.add_argument("--pose-stride", type=int, default=2, help="frame f uses pose (stride * f) %% cam_maxstep")
+    ap.add_argument("--bench-mode", default="frames", choices=["frames", "tile-parallel"],
+                    help="frames: every rank renders whole frames (frame f -> rank f %% N); tile-parallel: every step is ONE "
+                         "frame whose row bands are rendered by the N ranks (BASELINE config 5)")
+    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[i-1]: sets resolution / samples / cam_maxstep / bench mode / steps")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.config == 3:
+        args.height, args.width, args.samples, args.no_extras = 1080, 1920, 40, True
+    elif args.config == 4:     # the whole 256-pose orbit, sharded: K = 256 / N frames per rank
+        args.cam_maxstep, args.pose_stride = 256, 1
+        args.steps = max(1, 256 // world)
+    elif args.config == 5:
+        args.height, args.width, args.samples, args.bench_mode, args.no_extras = 2160, 3840, 40, "tile-parallel", True
+        args.steps = min(args.steps, 6)
+    return args
 
 
-def cpu_baseline(args, weights, scene_cpu_small, budget_s):
-    """The reference path as the CPU oracle executes it (reference-literal tiling, fp32, all host
-    cores): oracle/sdn_oracle.c for the three native ops + oracle/field_ref.py for the Python layers.
-    Bounded sample: ONE 158x158-ray tile (the reference's own tile size incl. apron) at 24 samples/ray
-    on a 256^2 synthetic scene; frames/s is extrapolated by ray count to the 40 tiles = 828 000
-    tile-rays the reference executes per 960x540 frame."""
+def cpu_baseline(args, weights, scene, z, genc):
+    """The reference path as the CPU oracle executes it (reference-literal tiling, fp32): oracle/sdn_oracle.c (pinned bit
+    for bit on the reference's own .cu sources compiled for the host, tests/test_ref_pin_cpu.py) for the three native
+    ops + oracle/field_ref.py (bit-identical to the imported reference Python on the goldens) for the Python layers.
+
+    Bounded sample of THIS workload: the benchmark scene and resolution, one pose; ray casting and the sky
+    pre-pass over the whole padded frame (as the reference does per frame) + 4 of the reference's 128-px tiles (two
+    frame corners incl. a ragged edge tile, the centre, one more interior tile); frames/s = 1 / (frame-wide part +
+    tile part x tile-rays of the frame / tile-rays sampled).  The thread count is calibrated first (8..128): the one
+    that renders a small tile fastest is used and reported as `cores`."""
     from oracle import field_ref as FR
     from oracle import oracle as O
     from scenedreamer_amd import camera, synth
+    from scenedreamer_amd.camera import tile_grid
     from scenedreamer_amd.renderer import load_label_lut
-    cores = CPU_THREADS
-    torch.set_num_threads(cores)
     lut = load_label_lut()["lut"]
-    sc = scene_cpu_small
-    pose = camera.eval_camera_poses(sc, maxstep=8)[2]
-    z = FR.style_mlp(weights, synth.make_style(8888))
-    genc = FR.world_encoder(weights, sc.current_height_map, sc.current_semantic_map)
-    hw = (128, 128)  # + 30 px apron = one reference tile of 158 x 158 rays
-    vox = sc.voxel_t.numpy()
+    vox = scene.voxel_t.cpu().numpy()
+    # z / global_enc: the per-trajectory codes (computed once per style / scene, not per frame) as the renderer holds them
+    pose = camera.eval_camera_poses(scene, maxstep=40)[8]
     p = (pose[0].numpy(), pose[1].numpy(), pose[2].numpy(), pose[3])
+    hw = (args.height, args.width)
+
+    def set_threads(n):
+        torch.set_num_threads(n)
+        O.set_num_threads(n)
+
+    # ---- calibration: one small reference tile per candidate thread count --------------------------------------
+    cal = {}
+    for n in [c for c in (8, 16, 32, 64, 128) if c <= CPU_THREADS_MAX] or [CPU_THREADS_MAX]:
+        set_threads(n)
+        t0 = time.time()
+        FR.render_frame_tiled(weights, lut, vox, p, (66, 66), args.samples, z, genc)
+        cal[n] = time.time() - t0
+    cores = min(cal, key=cal.get)
+    set_threads(cores)
+    # ---- the sample -----------------------------------------------------------------------------------------------
+    tiles_all, nh, nw = tile_grid([hw[0] + 30, hw[1] + 30], 30)
+    frame_tile_rays = sum((a[1] - a[0]) * (a[3] - a[2]) for a in tiles_all)
+    picks = list(dict.fromkeys([(0, 0), (nh - 1, nw - 1), (nh // 2, nw // 2), (min(1, nh - 1), max(0, nw - 2))]))
     t0 = time.time()
-    reps = 0
-    while True:
-        FR.render_frame_tiled(weights, lut, vox, p, hw, args.samples, z, genc)
-        reps += 1
-        if time.time() - t0 > budget_s or reps >= 16:      # ~10-30 s of host work (bounded sample)
-            break
-    dt = (time.time() - t0) / reps
-    tile_rays = 158 * 158
-    frame_tile_rays = 828000 if (args.height, args.width) == (540, 960) else None
-    if frame_tile_rays is None:
-        from scenedreamer_amd.camera import tile_grid
-        tiles, _, _ = tile_grid([args.height + 30, args.width + 30], 30)
-        frame_tile_rays = sum((a[1] - a[0]) * (a[3] - a[2]) for a in tiles)
-    fps = 1.0 / (dt * frame_tile_rays / tile_rays)
+    FR.render_frame_tiled(weights, lut, vox, p, hw, args.samples, z, genc, tiles=[])       # frame-wide part only
+    t_frame = time.time() - t0
+    t0 = time.time()
+    got = FR.render_frame_tiled(weights, lut, vox, p, hw, args.samples, z, genc, tiles=picks)
+    t_tiles = time.time() - t0 - t_frame
+    sampled = sum((im.shape[2] + 30) * (im.shape[3] + 30) for (_, _, im) in got.values())
+    fps = 1.0 / (t_frame + t_tiles * frame_tile_rays / sampled)
     return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"one 158x158-ray reference tile ({args.samples} samples/ray, 256^2 scene) rendered {reps}x in "
-                      f"{dt:.2f} s each by the CPU oracle; extrapolated by ray count to the {frame_tile_rays} "
-                      f"tile-rays of a {args.width}x{args.height} frame", "threads_oracle_c": O.num_threads(), "host_cpus": os.cpu_count()}
+            "sample": f"{args.width}x{args.height}, {args.samples} samples/ray, scene_size {args.scene_size}: ray casting + sky "
+                      f"pre-pass of the whole padded frame ({t_frame:.2f} s) + {len(picks)} of the reference's {nh * nw} "
+                      f"tiles = {sampled} of {frame_tile_rays} tile-rays ({t_tiles:.2f} s), extrapolated by tile-ray count",
+            "thread_calibration_s": {str(k): round(v, 3) for k, v in cal.items()}, "host_cpus": os.cpu_count(),
+            "native_ops": "oracle/sdn_oracle.c == the reference's .cu sources compiled for the host (bit for bit)"}
 
 
 def main():
@@ -137,12 +176,17 @@ def main():
         scene, weights, style = sdist.broadcast_state(scene, weights, style, dev, src=0)
     R = Renderer(weights, scene, dev)
     R.set_style(style)
-    maxstep = 40
+    maxstep = args.cam_maxstep
     poses = camera.eval_camera_poses(scene, maxstep=maxstep)
-    # every 2nd pose of the orbit, sharded round-robin over ranks (frame f -> rank f % world)
-    order = [(2 * i) % maxstep for i in range(maxstep)]
-    # weak scaling: step k renders global frames k*world .. k*world+world-1, rank r takes frame k*world + r
-    frame_pose = lambda k: poses[order[sdist.shard_frames(range(k * world, (k + 1) * world), rank, world)[0] % len(order)]]
+    # global frame f uses pose (stride * f) % maxstep (default: every 2nd pose of the 40-pose orbit)
+    order = [(args.pose_stride * i) % maxstep for i in range(maxstep)]
+    tile_parallel = args.bench_mode == "tile-parallel"
+    if tile_parallel:
+        # strong scaling inside a frame: step k = global frame k, every rank renders its row band of it
+        frame_pose = lambda k: poses[order[k % len(order)]]
+    else:
+        # weak scaling: step k renders global frames k*world .. k*world+world-1, rank r takes frame k*world + r
+        frame_pose = lambda k: poses[order[sdist.shard_frames(range(k * world, (k + 1) * world), rank, world)[0] % len(order)]]
     hw = (args.height, args.width)
     setup_s = time.time() - t_setup
 
@@ -151,8 +195,13 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
+    def render_one(pz):
+        if tile_parallel:
+            return sdist.render_frame_tile_parallel(R, pz, hw, args.samples, mode=mode)
+        return R.render_frame(pz, hw, args.samples, mode=mode, apron=args.apron)
+
     for k in range(args.warmup):
-        R.render_frame(frame_pose(k), hw, args.samples, mode=mode, apron=args.apron)
+        render_one(frame_pose(k))
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -160,8 +209,8 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     timed_poses = [frame_pose(args.warmup + k) for k in range(args.steps)]
-    if args.no_overlap or mode != "fused":
-        frames = (R.render_frame(pz, hw, args.samples, mode=mode, apron=args.apron) for pz in timed_poses)
+    if args.no_overlap or mode != "fused" or tile_parallel:
+        frames = (render_one(pz) for pz in timed_poses)
     else:   # all K frames are cast, evaluated and finished inside the timed region; frame k+1's ray casting runs beside frame k
         frames = R.render_frames(timed_poses, hw, args.samples, mode=mode, apron=args.apron)
     for k, img in enumerate(frames):
@@ -181,6 +230,8 @@ def main():
 
     # ---- delivered rate: frame in host memory as uint8 HWC (async D2H, PNG/MP4 encoding excluded), outside the timed region
     from scenedreamer_amd.output import to_uint8_hwc
+    if tile_parallel:
+        args.no_extras = True
     n_del = 0 if args.no_extras else min(args.steps, 10)
     pinned = [torch.empty((hw[0], hw[1], 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
     torch.cuda.synchronize()
@@ -193,7 +244,7 @@ def main():
 
     # ---- per-stage breakdown + roofline of the dominant kernel (outside the timed region) ----------
     stages = {}
-    for k in range(min(args.steps, 5)):
+    for k in range(0 if tile_parallel else min(args.steps, 5)):
         R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, timers=stages, apron=args.apron)
     stage_ms = {k: float(np.mean(v)) for k, v in stages.items()}
     # the same frames with the other apron setting (outside the timed region; reported for transparency)
@@ -207,24 +258,31 @@ def main():
         R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=other)
     torch.cuda.synchronize()
     other_ms = 1000.0 * (time.perf_counter() - t1) / n_other if n_other else None
-    roof, roof_grid = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
+    if tile_parallel:     # per-kernel records on this rank's band (every rank does 1/N of the frame)
+        roof, roof_grid = None, None
+    else:
+        roof, roof_grid = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
 
     if rank == 0:
-        fps = world * args.steps / elapsed
+        fps = (1 if tile_parallel else world) * args.steps / elapsed
         out = {
             # BASELINE.json's metric verbatim ("...; HBM GB/s": value = frames/s, the grid sampler's GB/s is in roofline_grid_sampler)
             "metric": f"rendered frames/sec @{args.width}\u00d7{args.height}, {args.samples} samples/ray, scene_size {args.scene_size}; HBM GB/s",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if tile_parallel else "weak",
             "vs_baseline": None, "dtype": R.compute_dtype(mode), "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height}, num_samples={args.samples}, "
-                                   f"scene_size={args.scene_size}, cam pattern 0 (every 2nd of 40 poses), "
-                                   f"1 frame per rank per step", "path": mode, "apron": args.apron,
+                                   f"scene_size={args.scene_size}, cam pattern 0 (pose stride {args.pose_stride} of {maxstep} poses), "
+                                   + ("1 frame per step, row bands over the ranks (tile-parallel)" if tile_parallel
+                                      else "1 frame per rank per step"),
+                       "baseline_config": args.config or (2 if (hw, args.samples, args.scene_size) == ((540, 960), 24, 2048) else None),
+                       "path": mode, "apron": "reference" if tile_parallel else args.apron,
                        "ray_casting_overlap": not (args.no_overlap or mode != "fused"),
                        "padded_rays": (hw[0] + 30) * (hw[1] + 30),
                        "field_rays": (hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30),
                        "samples_per_frame": ((hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30)) * args.samples,
-                       "parallelism": f"frames x{world}",
+                       "parallelism": f"row bands x{world}" if tile_parallel else f"frames x{world}",
                        "apron_note": "ray casting and the sky MLP always cover the reference's padded frame (15-px apron); "
                                      "'minimal' evaluates the field MLP and the CNN on the 4-px apron that can reach a kept "
                                      "pixel -- the image is bit-identical (tests/test_render_gpu.py, test_fullsize_gpu.py)"},
@@ -233,9 +291,7 @@ def main():
             "roofline": roof, "roofline_grid_sampler": roof_grid,
         }
         if world == 1 and not args.no_cpu_baseline:
-            small = synth.make_scene(256, 3407)
-            out["cpu_baseline"] = cpu_baseline(args, weights if isinstance(weights, dict) else None, small,
-                                               args.cpu_budget_s)
+            out["cpu_baseline"] = cpu_baseline(args, weights, scene, R.z.cpu().numpy(), R.global_enc.cpu().numpy())
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

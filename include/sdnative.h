@@ -145,16 +145,23 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, int32_t n_rays,
                      int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
                      float *dist, uint8_t *label, uint8_t *rayflag, sdn_stream_t stream);
-/* sky_c dev f32 [R,64] = sky_net output per ray; net_out dev f32 [R,64]; n_workgroups <= 0 -> one per CU */
+/* sky_c dev f32 [R,64] = sky_net output per ray; net_out dev f32 [R,64]; n_workgroups <= 0 -> one per CU.
+ * colour_terms: f16 split terms of the colour layers fc_5 / fc_6: 3 (like every other layer) or 2 (without Whi.Xlo).
+ * term_eps: early ray termination -- a 32-ray group stops sampling once the transmittance of all its rays is below
+ *   term_eps (changes net_out by at most 2 * term_eps); 0 = off (the reference evaluates every sample).
+ * passes: optional dev u8 [ceil(ceil(R / 8) / 4)], number of 4-sample passes every 32-ray group went through. */
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
-                  int32_t n_workgroups, sdn_stream_t stream);
+                  int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, sdn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Render CNN: the convolutions of RenderCNN (imaginaire/generators/gancraft_base.py:175-225, forward :202-225) on MFMA
- * with the field MLP's 3-term f16 split: 3x3 256->256 (conv2a/2b/3a/3b; taps = 9, cin = 256) and 1x1 cin->256
+ * as f16 products with f32 accumulation: 3x3 256->256 (conv2a/2b/3a/3b; taps = 9, cin = 256) and 1x1 cin->256
  * (conv1 64->256, conv4a/4b; taps = 1); the final conv4 (256->3, 1x1) + tanh (:221, :603) is an optional projection
  * in the epilogue.
+ * terms = 3: every product is Whi.Xhi + Wlo.Xhi + Whi.Xlo (the field MLP's split, ~2^-21 relative);
+ * terms = 1: Whi.Xhi only, hi = round-to-nearest f16 (3x3 layers only; in_lo may be NULL).  The weights must have been
+ * packed with the same `terms`.
  * Activations travel between the convolutions as two f16 planes (hi, lo) [cin/16 chunks][Hb*Wb][16 channels] with a zero
  * border (extent from sdn_conv_plane_dims; the caller zero-fills the planes ONCE, kernels never write the border or
  * pixels outside the H x W frame); fp32 tensors are rows [H*W][256] (channels last).
@@ -163,14 +170,15 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
  *   img = tanh(proj_w . y + proj_b)                                                optional, [3][H*W]
  */
 void sdn_conv_plane_dims(int H, int W, int *Hb, int *Wb);
-/* 0 for an unsupported (cin, taps) */
-size_t sdn_conv_packed_weight_bytes(int cin, int taps);
+/* 0 for an unsupported (cin, taps, terms) */
+size_t sdn_conv_packed_weight_bytes(int cin, int taps, int terms);
 /* w_oihw dev f32 [256,cin,k,k] (k*k = taps) -> packed dev */
-int sdn_conv_pack_weights(const float *w_oihw, int cin, int taps, void *packed, sdn_stream_t stream);
+int sdn_conv_pack_weights(const float *w_oihw, int cin, int taps, int terms, void *packed, sdn_stream_t stream);
 /* x dev f32 [H*W,channels] -> hi/lo planes */
 int sdn_conv_planes_from_f32(const float *x, int channels, void *out_hi, void *out_lo, int H, int W, sdn_stream_t stream);
-/* outputs: any of (out_hi,out_lo) planes, out_f32 rows [H*W,256], out_img [3,H*W] (with proj_w [3,256], proj_b [3]) */
-int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void *packed, const float *bias,
+/* outputs: any of out_hi (+ out_lo; NULL when every consumer is 1-term) planes, out_f32 rows [H*W,256], out_img [3,H*W]
+ * (with proj_w [3,256], proj_b [3]) */
+int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms, const void *packed, const float *bias,
              const float *resid, const void *resid_hi, const void *resid_lo, const float *mod_w, const float *mod_b,
              void *out_hi, void *out_lo, float *out_f32, const float *proj_w, const float *proj_b, float *out_img, int H,
              int W, int n_workgroups, sdn_stream_t stream);

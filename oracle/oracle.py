@@ -46,6 +46,10 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))
+
+
 def camera_frame(cam_dir, cam_up):
     out = np.empty(9, np.float32)
     lib().oracle_camera_frame(_p(_f32(cam_dir)), _p(_f32(cam_up)), _p(out))

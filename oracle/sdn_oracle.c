@@ -362,6 +362,14 @@ ORACLE_API void oracle_grid_encode_bwd(const float *grad_all, const float *input
     }
 }
 
+ORACLE_API void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 ORACLE_API int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -48,17 +48,17 @@ _SIGNATURES = {
     "sdn_field_encode": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "sdn_field_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
-                            c_p]),
+                            ctypes.c_float, c_p, ctypes.c_int32, c_p]),
     "sdn_sky_packed_weight_bytes": (ctypes.c_size_t, []),
     "sdn_sky_consts_floats": (ctypes.c_size_t, []),
     "sdn_sky_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_sky_partial_rows": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
     "sdn_sky_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, c_p]),
     "sdn_conv_plane_dims": (None, [c_i, c_i, c_p, c_p]),
-    "sdn_conv_packed_weight_bytes": (ctypes.c_size_t, [c_i, c_i]),
-    "sdn_conv_pack_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    "sdn_conv_packed_weight_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
+    "sdn_conv_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "sdn_conv_planes_from_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
-    "sdn_conv": (c_i, [c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "sdn_conv": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "sdn_debug_mfma_probe": (c_i, [c_p, c_p, c_p, c_p]),
 }
 # entry points added by later kernels register themselves here (name -> (restype, argtypes))

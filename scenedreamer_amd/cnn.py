@@ -1,8 +1,13 @@
 """Host side of the MFMA render CNN (csrc/cnn.hip): RenderCNN.forward + tanh
 (imaginaire/generators/gancraft_base.py:202-225, :588-603).  Seven launches of one kernel family: conv1 (1x1, 64->256),
 conv2a/2b/3a/3b (3x3), conv4a/4b (1x1) with conv4 (256->3) + tanh folded into conv4b's epilogue; activations travel
-as f16 hi/lo planes, residual inputs as fp32 rows."""
+as f16 hi/lo planes.
+
+Precision profile (`terms3x3`): the 1x1 layers always use the 3-term f16 split; the four 3x3 layers use ONE term
+(Whi.Xhi, both rounded to nearest) by default -- measured image error vs the fp32 CNN ~7e-5 rms / <5e-4 max at a third
+of the MFMAs (tools/precision_study.py) -- or the 3-term split with terms3x3=3 (< 2e-5)."""
 import ctypes
+import os
 
 import torch
 
@@ -13,8 +18,12 @@ _LAYERS = {"conv1": (64, 1), "conv2a": (256, 9), "conv2b": (256, 9), "conv3a": (
 
 
 class MfmaCNN:
-    def __init__(self, R):
+    def __init__(self, R, terms3x3=None):
         self.R = R
+        if terms3x3 is None:
+            terms3x3 = int(os.environ.get("SDN_CNN_TERMS", "1"))
+        assert terms3x3 in (1, 3)
+        self.terms = {n: (terms3x3 if taps == 9 else 3) for n, (_, taps) in _LAYERS.items()}
         lib = capi.lib()
         w = R.w
         self.packed = {}
@@ -22,8 +31,8 @@ class MfmaCNN:
             for n, (cin, taps) in _LAYERS.items():
                 wt = w[f"denoiser.{n}.weight"]
                 assert tuple(wt.shape[:2]) == (256, cin) and wt.shape[2] * wt.shape[3] == taps, (n, tuple(wt.shape))
-                buf = torch.empty(lib.sdn_conv_packed_weight_bytes(cin, taps), dtype=torch.uint8, device=R.dev)
-                capi.check(lib.sdn_conv_pack_weights(wt.contiguous().data_ptr(), cin, taps, buf.data_ptr(),
+                buf = torch.empty(lib.sdn_conv_packed_weight_bytes(cin, taps, self.terms[n]), dtype=torch.uint8, device=R.dev)
+                capi.check(lib.sdn_conv_pack_weights(wt.contiguous().data_ptr(), cin, taps, self.terms[n], buf.data_ptr(),
                                                      capi.current_stream(R.dev)), "sdn_conv_pack_weights")
                 self.packed[n] = buf
         self.w4 = w["denoiser.conv4.weight"].reshape(3, 256).contiguous()
@@ -55,11 +64,13 @@ class MfmaCNN:
         p = lambda t: t.data_ptr() if t is not None else None
         cin, taps = _LAYERS[name]
         with torch.cuda.device(self.R.dev):
-            capi.check(capi.lib().sdn_conv(src[0].data_ptr(), src[1].data_ptr(), cin, taps, self.packed[name].data_ptr(),
+            capi.check(capi.lib().sdn_conv(src[0].data_ptr(), src[1].data_ptr(), cin, taps, self.terms[name],
+                                           self.packed[name].data_ptr(),
                                            p(bias), p(resid), resid_planes[0].data_ptr() if resid_planes else None,
                                            resid_planes[1].data_ptr() if resid_planes else None,
                                            p(mod[0]) if mod else None, p(mod[1]) if mod else None,
-                                           dst[0].data_ptr() if dst else None, dst[1].data_ptr() if dst else None, p(out32),
+                                           dst[0].data_ptr() if dst else None,
+                                           dst[1].data_ptr() if dst and dst[1] is not None else None, p(out32),
                                            p(proj[0]) if proj else None, p(proj[1]) if proj else None, p(img),
                                            H, W, 0, capi.current_stream(self.R.dev)), "sdn_conv")
 
@@ -79,9 +90,11 @@ class MfmaCNN:
         # the running activation y lives in planes A (hi + lo f16 = y to 2^-22) and is updated in place by the
         # residual convolutions; planes B hold the inner activation of each residual block
         self._conv(B, "conv1", H, W, bias=bias("conv1"), dst=A)                                    # y = act(conv1(x))
-        self._conv(A, "conv2a", H, W, bias=bias("conv2a"), dst=B)                                  # act(conv2a(y))
+        # the inner activations are consumed only by conv2b / conv3b: no lo plane when those are 1-term
+        inner = (B[0], None) if self.terms["conv2b"] == 1 else B
+        self._conv(A, "conv2a", H, W, bias=bias("conv2a"), dst=inner)                              # act(conv2a(y))
         self._conv(B, "conv2b", H, W, bias=bias("conv2b"), resid_planes=A, mod=(a[0], a[1]), dst=A)
-        self._conv(A, "conv3a", H, W, bias=bias("conv3a"), dst=B)
+        self._conv(A, "conv3a", H, W, bias=bias("conv3a"), dst=inner)
         self._conv(B, "conv3b", H, W, bias=bias("conv3b"), resid_planes=A, mod=(a[2], a[3]), dst=A)
         self._conv(A, "conv4a", H, W, bias=bias("conv4a"), dst=B)
         self._conv(B, "conv4b", H, W, bias=bias("conv4b"), resid_planes=A, proj=(self.w4, self.b4), img=img)

@@ -19,7 +19,13 @@
 //     wait ever drains the pipeline (ordinary loads of B would: vmcnt completes in order);
 //   * epilogue variants: bias + LeakyReLU -> f16 planes (conv2a/3a);  residual + style FiLM + LeakyReLU ->
 //     fp32 rows and/or f16 planes (conv2b/3b, gancraft_base.py:197-200, :213-217).
-// Roofline: MFMA (f16 dense peak); 3456 MFMAs per wave per 32 pixels.
+// Precision (tools/precision_study.py): TERMS = 3 evaluates every product as Whi.Xhi + Wlo.Xhi + Whi.Xlo;
+// TERMS = 1 (the four 3x3 convolutions by default) keeps Whi.Xhi only, with BOTH hi parts rounded to nearest
+// (v_cvt_pk_f16_f32; round-toward-zero doubles the error and biases it).  Nothing downstream of the 3x3 layers
+// amplifies their rounding noise, so the image moves by ~7e-5 rms / ~4e-4 max while the layer issues a third of
+// the MFMAs and reads half the bytes.  In the 1-term layout a ring slot carries TWO k-steps (k0 in the "hi" position,
+// k1 in the "lo" position of the 3-term layout): data movement per slot is unchanged, a unit is 4 MFMAs instead of 6.
+// Roofline: MFMA (f16 dense peak); 3456 (TERMS = 3) / 1152 (TERMS = 1) MFMAs per wave per 32 pixels for a 3x3 layer.
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
@@ -37,7 +43,6 @@ typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const char glb_char;
 
 constexpr int CH = 256;
-constexpr int KSTEPS_3X3 = 9 * 16;        // 144 k-steps of the 3x3 256 -> 256 convolution
 constexpr int A_BYTES = 16384;            // weight fragments of one k-step (8 row blocks, hi + lo)
 constexpr int B_BYTES = 2048;             // one wave's activation fragments of one k-step (hi + lo)
 constexpr int WAVES = 8;                  // 2 waves per SIMD: one wave's LDS/DMA/barrier time is the other's MFMA time
@@ -51,7 +56,7 @@ constexpr int PATCH_W = 16, PATCH_H = 16; // pixels per workgroup: 2 x 4 wave ti
 struct ConvParams {
     const _Float16 *xh, *xl;   // input planes [16][Hb*Wb][16], zero border and zero outside the frame
     const char *wpk;           // packed weights, ksteps * 16 KiB
-    int ksteps;                // TAPS * (input channels / 16)
+    int ksteps;                // ring slots per patch: TAPS * (input channels / 16) k-steps, two per slot when TERMS == 1
     const float *bias;         // [256] or nullptr
     const float *resid;        // fp32 [H*W][256] or nullptr
     const _Float16 *rh, *rl;   // residual as hi/lo planes (same layout as the output planes; may alias them) or nullptr
@@ -77,10 +82,30 @@ __device__ __forceinline__ float vmax(float a, float b) {
     return r;
 }
 
+// two f32 -> packed f16, round to nearest even: one v_cvt_pk_f16_f32 (new in gfx950)
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2v cvt_rtn(float a, float b) {
+    return __builtin_convertvector(float2v{a, b}, half2v);
+}
+
 // DMA of k-step `kt` of a pass into ring position `pos`
 // one of the 4 DMA pieces a wave contributes to ring position `pos` for k-step `kt`: 0, 1 = its 2 KiB of the weight
 // fragments, 2 / 3 = its own activation fragments (hi / lo plane)
-template <int TAPS, int PIECE>
+template <int TAPS>
+__device__ __forceinline__ long tap_offset(const ConvParams &p, int k) {
+    // k order is channel-chunk major: k = 9*s + tap.  The 9 taps of one 16-channel chunk re-read the same
+    // (patch + halo) x 32 B region, which stays in L1/L2; with tap-major order every tap re-streamed the whole
+    // patch from the Infinity Cache (measured 3.2 GB fetched per launch for 0.58 GB of input).
+    if constexpr (TAPS == 9) {
+        const int s = k / 9, tap = k - 9 * s;
+        return ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * 32 + (long)s * p.chunk_bytes;
+    } else {
+        return (long)k * p.chunk_bytes;   // 1x1: k-step = channel chunk
+    }
+}
+
+template <int TAPS, int TERMS, int PIECE>
 __device__ __forceinline__ void issue_piece(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
     if constexpr (PIECE < 2) {
         // (the instruction offset applies to the global AND the LDS address)
@@ -89,28 +114,24 @@ __device__ __forceinline__ void issue_piece(char *lds, const ConvParams &p, int 
         if constexpr (PIECE == 0) __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 0, 0);
         else __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 1024, 0);
     } else {
-        // k order is channel-chunk major: kt = 9*s + tap.  The 9 taps of one 16-channel chunk re-read the same
-        // (patch + halo) x 32 B region, which stays in L1/L2; with tap-major order every tap re-streamed the whole
-        // patch from the Infinity Cache (measured 3.2 GB fetched per launch for 0.58 GB of input).
-        long toff;
-        if constexpr (TAPS == 9) {
-            const int s = kt / 9, tap = kt - 9 * s;
-            toff = ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * 32 + (long)s * p.chunk_bytes;
-        } else {
-            toff = (long)kt * p.chunk_bytes;   // 1x1: k-step = channel chunk
-        }
         char *bdst = lds + pos * SLOT_BYTES + A_BYTES + wave * B_BYTES;
-        if constexpr (PIECE == 2) __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + toff), (lds_char *)bdst, 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xl + boff + toff), (lds_char *)(bdst + 1024), 16, 0, 0);
+        if constexpr (TERMS == 3) {   // hi and lo plane of k-step kt
+            const long toff = tap_offset<TAPS>(p, kt);
+            if constexpr (PIECE == 2) __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + toff), (lds_char *)bdst, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xl + boff + toff), (lds_char *)(bdst + 1024), 16, 0, 0);
+        } else {                      // hi plane of k-steps 2 kt and 2 kt + 1
+            if constexpr (PIECE == 2) __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + tap_offset<TAPS>(p, 2 * kt)), (lds_char *)bdst, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + tap_offset<TAPS>(p, 2 * kt + 1)), (lds_char *)(bdst + 1024), 16, 0, 0);
+        }
     }
 }
 
-template <int TAPS>
+template <int TAPS, int TERMS>
 __device__ __forceinline__ void issue_slot(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
-    issue_piece<TAPS, 0>(lds, p, pos, kt, wave, lane, boff);
-    issue_piece<TAPS, 1>(lds, p, pos, kt, wave, lane, boff);
-    issue_piece<TAPS, 2>(lds, p, pos, kt, wave, lane, boff);
-    issue_piece<TAPS, 3>(lds, p, pos, kt, wave, lane, boff);
+    issue_piece<TAPS, TERMS, 0>(lds, p, pos, kt, wave, lane, boff);
+    issue_piece<TAPS, TERMS, 1>(lds, p, pos, kt, wave, lane, boff);
+    issue_piece<TAPS, TERMS, 2>(lds, p, pos, kt, wave, lane, boff);
+    issue_piece<TAPS, TERMS, 3>(lds, p, pos, kt, wave, lane, boff);
 }
 
 // Fragment reads are inline asm with hand-counted s_waitcnt: behind a pending LDS-DMA the compiler's own wait
@@ -144,7 +165,7 @@ __device__ __forceinline__ void lds_wait() {
 // activation fragments of the next k-step (U == 2) and the weight fragments of the unit two units on.  The fragment
 // reads are the last LDS operations of a unit: "lgkmcnt(reads of the previous unit)" at the start of a unit means
 // this unit's fragments have landed.
-template <int TAPS, int DBG, int U>
+template <int TAPS, int TERMS, int DBG, int U>
 __device__ __forceinline__ void conv_unit(char *lds, const ConvParams &p, f32x16 (&acc)[8], half8 (&a)[4][4], half8 (&bcur)[2],
                                           half8 (&bnext)[2], unsigned slot, unsigned slot_n, unsigned b_off, int pos_issue,
                                           int kt_issue, long boff_issue, int wave, int lane) {
@@ -155,13 +176,24 @@ __device__ __forceinline__ void conv_unit(char *lds, const ConvParams &p, f32x16
     constexpr int OFF = ((U + 2) & 3) * 4096;
     lds_wait<U == 3 ? 6 : 4>();
 #define SDN_GAP(K) \
-    if constexpr (K == 0 && !(DBG & 1)) issue_piece<TAPS, U>(lds, p, pos_issue, kt_issue, wave, lane, boff_issue); \
+    if constexpr (K == 0 && !(DBG & 1)) issue_piece<TAPS, TERMS, U>(lds, p, pos_issue, kt_issue, wave, lane, boff_issue); \
     if constexpr (K == 0 && U == 2) { ds_read16<0>(bnext[0], slot_n + b_off); ds_read16<1024>(bnext[1], slot_n + b_off); } \
     if constexpr (K >= 1 && K <= 4) ds_read16<OFF + (K - 1) * 1024>(nx[K - 1], src); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DBG & 16) {
         asm volatile("" ::"v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]), "v"(bcur[0]), "v"(bcur[1]));
         SDN_GAP(0) SDN_GAP(1) SDN_GAP(2) SDN_GAP(3) SDN_GAP(4)
+    } else if constexpr (TERMS == 1) {
+        // fragments: au[0] = (ib, k0), au[1] = (ib, k1), au[2] = (ib+1, k0), au[3] = (ib+1, k1); bcur[0] = k0, bcur[1] = k1
+        acc[ib] = mfma16(au[0], bcur[0], acc[ib]);
+        __builtin_amdgcn_sched_barrier(0);
+        SDN_GAP(0)
+        acc[ib + 1] = mfma16(au[2], bcur[0], acc[ib + 1]);
+        SDN_GAP(1) SDN_GAP(2)
+        acc[ib] = mfma16(au[1], bcur[1], acc[ib]);
+        SDN_GAP(3)
+        acc[ib + 1] = mfma16(au[3], bcur[1], acc[ib + 1]);
+        SDN_GAP(4)
     } else {
         acc[ib] = mfma16(au[0], bcur[0], acc[ib]);
         __builtin_amdgcn_sched_barrier(0);   // the matrix instruction first: the gap's address arithmetic runs in its shadow
@@ -188,7 +220,7 @@ __device__ __forceinline__ long lane_pixel_offset(const ConvParams &p, int grp, 
     return ((long)(py + 1) * p.Wb + (px + 1)) * 32 + h * 16;   // byte offset inside chunk 0
 }
 
-template <int TAPS, int DBG>
+template <int TAPS, int DBG, int TERMS>
 __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[NSLOT * SLOT_BYTES];
     const int lane = threadIdx.x & 63;
@@ -206,7 +238,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
     int pos_issue = 0, pos_use = 0;
 #pragma unroll
     for (int q = 0; q < AHEAD; q++) {
-        issue_slot<TAPS>(lds, p, pos_issue, q, wave, lane, boff);
+        issue_slot<TAPS, TERMS>(lds, p, pos_issue, q, wave, lane, boff);
         pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
     }
     const int ksteps = p.ksteps;
@@ -253,10 +285,10 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                     lds_unit<1>(slot, a[1]);
                     primed = true;
                 }
-                conv_unit<TAPS, DBG, 0>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
-                conv_unit<TAPS, DBG, 1>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
-                conv_unit<TAPS, DBG, 2>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
-                conv_unit<TAPS, DBG, 3>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 0>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 1>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 2>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 3>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
             }
         }
         // the prefetches of the (possibly non-existent) next patch's first units must land before registers are reused
@@ -320,16 +352,18 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                         *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
                     }
                     if (p.oh) {
+                        // hi = round-to-nearest f16 (v_cvt_pk_f16_f32): a 1-term consumer sees half the error of a
+                        // truncated hi, a 3-term consumer does not care (lo absorbs the remainder either way)
                         half8 hv, lv;
 #pragma unroll
                         for (int e = 0; e < 8; e += 2) {
-                            const fp16x2 hp = __builtin_amdgcn_cvt_pkrtz(v[e], v[e + 1]);
-                            const fp16x2 lp = __builtin_amdgcn_cvt_pkrtz(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
-                            hv[e] = (_Float16)hp[0]; hv[e + 1] = (_Float16)hp[1];
-                            lv[e] = (_Float16)lp[0]; lv[e + 1] = (_Float16)lp[1];
+                            const half2v hp = cvt_rtn(v[e], v[e + 1]);
+                            hv[e] = hp[0]; hv[e + 1] = hp[1];
+                            const half2v lp = cvt_rtn(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
+                            lv[e] = lp[0]; lv[e + 1] = lp[1];
                         }
                         *reinterpret_cast<half8 *>(p.oh + po) = hv;
-                        *reinterpret_cast<half8 *>(p.ol + po) = lv;
+                        if (p.ol) *reinterpret_cast<half8 *>(p.ol + po) = lv;   // not needed when every consumer is 1-term
                     }
                 }
             }
@@ -355,27 +389,41 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
 }
 
 // ---- weight packing: W [256][cin][taps] (PyTorch OIHW) -> [k-step t = taps*s + tap][unit][frag][64 lanes][8] ----------
-__global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict__ W, half8 *__restrict__ out, int cin, int taps) {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // (t, ib, lane)
-    if (g >= (size_t)(cin / 16) * taps * 8 * 64) return;
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float *__restrict__ W, half8 *__restrict__ out, int cin, int taps, int terms) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // (t, ib, lane), t = ring slot
+    const int nslots = (cin / 16) * taps / (terms == 1 ? 2 : 1);
+    if (g >= (size_t)nslots * 8 * 64) return;
     const int lane = (int)(g % 64);
     const int ib = (int)((g / 64) % 8);
     const int t = (int)(g / (64 * 8));
-    const int s = t / taps, tap = t - taps * s;   // same k order as issue_slot
     // MFMA row i of a 32-row block carries channel 16*((i>>2)&1) + 4*(i>>3) + (i&3) of the block: the C/D register
     // layout (row = (r&3) + 8*(r>>2) + 4*h) then gives lane half h the 16 CONSECUTIVE channels 16*h + r (epilogue)
     const int i32 = lane & 31, h = lane >> 5;
     const int co = 32 * ib + 16 * ((i32 >> 2) & 1) + 4 * (i32 >> 3) + (i32 & 3);
     half8 hi, lo;
+    if (terms == 1) {   // slot t = k-steps 2t ("hi" position) and 2t+1 ("lo" position), round-to-nearest f16 of the weight
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int ci = 16 * s + 8 * h + e;
-        const float v = W[((size_t)co * cin + ci) * taps + tap];
-        const _Float16 vh = (_Float16)v;
-        hi[e] = vh;
-        lo[e] = (_Float16)(v - (float)vh);
+        for (int kk = 0; kk < 2; kk++) {
+            const int k = 2 * t + kk, s = k / taps, tap = k - taps * s;   // same k order as tap_offset
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const _Float16 vh = (_Float16)W[((size_t)co * cin + 16 * s + 8 * h + e) * taps + tap];
+                if (kk == 0) hi[e] = vh;
+                else lo[e] = vh;
+            }
+        }
+    } else {
+        const int s = t / taps, tap = t - taps * s;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int ci = 16 * s + 8 * h + e;
+            const float v = W[((size_t)co * cin + ci) * taps + tap];
+            const _Float16 vh = (_Float16)v;
+            hi[e] = vh;
+            lo[e] = (_Float16)(v - (float)vh);
+        }
     }
-    // unit = ib / 2; fragments (ib,hi) (ib,lo) (ib+1,hi) (ib+1,lo)
+    // unit = ib / 2; fragments (ib,hi) (ib,lo) (ib+1,hi) (ib+1,lo)   [1-term: (ib,k0) (ib,k1) (ib+1,k0) (ib+1,k1)]
     const size_t base = ((size_t)t * 16 + (size_t)(ib / 2) * 4 + (ib & 1) * 2) * 64 + lane;
     out[base] = hi;
     out[base + 64] = lo;
@@ -390,12 +438,12 @@ __global__ __launch_bounds__(256) void planes_kernel(const float *__restrict__ x
         const int c0 = (int)(i % (C / 4)) * 4;
         const int y = (int)(pix / W), xx = (int)(pix % W);
         const float4 v = *reinterpret_cast<const float4 *>(x + pix * C + c0);
-        const fp16x2 h0 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y), h1 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
-        const fp16x2 l0 = __builtin_amdgcn_cvt_pkrtz(v.x - (float)h0[0], v.y - (float)h0[1]);
-        const fp16x2 l1 = __builtin_amdgcn_cvt_pkrtz(v.z - (float)h1[0], v.w - (float)h1[1]);
+        const half2v h0 = cvt_rtn(v.x, v.y), h1 = cvt_rtn(v.z, v.w);
+        const half2v l0 = cvt_rtn(v.x - (float)h0[0], v.y - (float)h0[1]);
+        const half2v l1 = cvt_rtn(v.z - (float)h1[0], v.w - (float)h1[1]);
         half4 hv, lv;
-        hv[0] = (_Float16)h0[0]; hv[1] = (_Float16)h0[1]; hv[2] = (_Float16)h1[0]; hv[3] = (_Float16)h1[1];
-        lv[0] = (_Float16)l0[0]; lv[1] = (_Float16)l0[1]; lv[2] = (_Float16)l1[0]; lv[3] = (_Float16)l1[1];
+        hv[0] = h0[0]; hv[1] = h0[1]; hv[2] = h1[0]; hv[3] = h1[1];
+        lv[0] = l0[0]; lv[1] = l0[1]; lv[2] = l1[0]; lv[3] = l1[1];
         const long o = ((long)(c0 >> 4) * ((long)Hb * Wb) + (long)(y + 1) * Wb + (xx + 1)) * 16 + (c0 & 15);
         *reinterpret_cast<half4 *>(oh + o) = hv;
         *reinterpret_cast<half4 *>(ol + o) = lv;
@@ -412,16 +460,25 @@ void sdn_conv_plane_dims(int H, int W, int *Hb, int *Wb) {
     *Wb = sdn::div_up(W, PATCH_W) * PATCH_W + 2;
 }
 
-static bool conv_shape_ok(int cin, int taps) { return (taps == 9 && cin == 256) || (taps == 1 && cin >= 64 && cin <= 256 && cin % 16 == 0); }
+static bool conv_shape_ok(int cin, int taps, int terms) {
+    if (terms != 1 && terms != 3) return false;
+    if (terms == 1 && !(taps == 9 && cin == 256)) return false;   // the 1-term kernel exists for the 3x3 layers
+    return (taps == 9 && cin == 256) || (taps == 1 && cin >= 64 && cin <= 256 && cin % 16 == 0);
+}
+#define SDN_CONV_SHAPES "supported: 3x3 256->256 (terms 1 or 3) and 1x1 (64..256, multiple of 16)->256 (terms 3)"
 
-size_t sdn_conv_packed_weight_bytes(int cin, int taps) { return conv_shape_ok(cin, taps) ? (size_t)(cin / 16) * taps * A_BYTES : 0; }
+static int conv_slots(int cin, int taps, int terms) { return (cin / 16) * taps / (terms == 1 ? 2 : 1); }
 
-int sdn_conv_pack_weights(const float *w_oihw, int cin, int taps, void *packed, sdn_stream_t stream) {
+size_t sdn_conv_packed_weight_bytes(int cin, int taps, int terms) {
+    return conv_shape_ok(cin, taps, terms) ? (size_t)conv_slots(cin, taps, terms) * A_BYTES : 0;
+}
+
+int sdn_conv_pack_weights(const float *w_oihw, int cin, int taps, int terms, void *packed, sdn_stream_t stream) {
     SDN_REQUIRE(w_oihw && packed, "sdn_conv_pack_weights: null pointer");
-    SDN_REQUIRE(conv_shape_ok(cin, taps), "sdn_conv_pack_weights: supported shapes are 3x3 256->256 and 1x1 (64..256, multiple of 16)->256");
-    const size_t n = (size_t)(cin / 16) * taps * 8 * 64;
+    SDN_REQUIRE(conv_shape_ok(cin, taps, terms), "sdn_conv_pack_weights: " SDN_CONV_SHAPES);
+    const size_t n = (size_t)conv_slots(cin, taps, terms) * 8 * 64;
     hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)sdn::div_up<size_t>(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, (half8 *)packed, cin, taps);
+                       w_oihw, (half8 *)packed, cin, taps, terms);
     return sdn::check_launch("sdn_conv_pack_weights");
 }
 
@@ -435,13 +492,15 @@ int sdn_conv_planes_from_f32(const float *x, int channels, void *out_hi, void *o
     return sdn::check_launch("sdn_conv_planes_from_f32");
 }
 
-int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void *packed, const float *bias, const float *resid,
+int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms, const void *packed, const float *bias, const float *resid,
              const void *resid_hi, const void *resid_lo, const float *mod_w, const float *mod_b, void *out_hi, void *out_lo,
              float *out_f32, const float *proj_w, const float *proj_b, float *out_img, int H, int W, int n_workgroups,
              sdn_stream_t stream) {
-    SDN_REQUIRE(in_hi && in_lo && packed && H > 0 && W > 0, "sdn_conv: bad argument");
-    SDN_REQUIRE(conv_shape_ok(cin, taps), "sdn_conv: supported shapes are 3x3 256->256 and 1x1 (64..256, multiple of 16)->256");
-    SDN_REQUIRE((out_hi && out_lo) || out_f32 || out_img, "sdn_conv: no output requested");
+    SDN_REQUIRE(in_hi && packed && H > 0 && W > 0, "sdn_conv: bad argument");
+    SDN_REQUIRE(conv_shape_ok(cin, taps, terms), "sdn_conv: " SDN_CONV_SHAPES);
+    SDN_REQUIRE(in_lo || terms == 1, "sdn_conv: the 3-term product needs the lo input plane");
+    SDN_REQUIRE(out_hi || out_f32 || out_img, "sdn_conv: no output requested");
+    SDN_REQUIRE(out_hi || !out_lo, "sdn_conv: out_lo without out_hi");
     SDN_REQUIRE((mod_w == nullptr) == (mod_b == nullptr), "sdn_conv: mod_w and mod_b go together");
     SDN_REQUIRE((resid_hi == nullptr) == (resid_lo == nullptr) && !(resid && resid_hi), "sdn_conv: one residual form at most");
     SDN_REQUIRE(!(resid_hi && (resid_hi == in_hi || resid_lo == in_lo)), "sdn_conv: the residual planes must not be the input planes");
@@ -449,7 +508,7 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void
                 "sdn_conv: proj_w, proj_b and out_img go together");
     ConvParams p;
     p.xh = (const _Float16 *)in_hi; p.xl = (const _Float16 *)in_lo; p.wpk = (const char *)packed;
-    p.ksteps = (cin / 16) * taps;
+    p.ksteps = conv_slots(cin, taps, terms);
     p.bias = bias; p.resid = resid; p.rh = (const _Float16 *)resid_hi; p.rl = (const _Float16 *)resid_lo; p.mod_w = mod_w; p.mod_b = mod_b;
     p.oh = (_Float16 *)out_hi; p.ol = (_Float16 *)out_lo; p.of32 = out_f32;
     p.proj_w = proj_w; p.proj_b = proj_b; p.img = out_img;
@@ -462,7 +521,11 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void
     int wg = n_workgroups > 0 ? n_workgroups : 256;
     if (wg > p.n_groups) wg = p.n_groups;
     if (taps == 1) {
-        hipLaunchKernelGGL((conv_kernel<1, 0>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL((conv_kernel<1, 0, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
+        return sdn::check_launch("sdn_conv");
+    }
+    if (terms == 1) {
+        hipLaunchKernelGGL((conv_kernel<9, 0, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
         return sdn::check_launch("sdn_conv");
     }
     static const int dbg = [] {
@@ -471,13 +534,13 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, const void
     }();
     switch (dbg) {
 #ifdef SDN_MLP_ABLATION
-        case 1: hipLaunchKernelGGL((conv_kernel<9, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 2: hipLaunchKernelGGL((conv_kernel<9, 2>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 3: hipLaunchKernelGGL((conv_kernel<9, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 16: hipLaunchKernelGGL((conv_kernel<9, 16>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 19: hipLaunchKernelGGL((conv_kernel<9, 19>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 1: hipLaunchKernelGGL((conv_kernel<9, 1, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL((conv_kernel<9, 2, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 3: hipLaunchKernelGGL((conv_kernel<9, 3, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 16: hipLaunchKernelGGL((conv_kernel<9, 16, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        case 19: hipLaunchKernelGGL((conv_kernel<9, 19, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
 #endif
-        default: hipLaunchKernelGGL((conv_kernel<9, 0>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL((conv_kernel<9, 0, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
     }
     return sdn::check_launch("sdn_conv");
 }

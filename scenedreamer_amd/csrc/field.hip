@@ -105,6 +105,8 @@ struct MlpParams {
     const float *sky_c;        // [R, 64] sky_net output per ray
     float *net_out;            // [R, 64]
     int32_t R, ns, nch, n_tiles;
+    float term_depth;          // early ray termination: optical depth -ln(eps) beyond which a ray is opaque; <= 0: off
+    uint8_t *passes;           // optional [ceil(n_tiles / 4)]: passes every 32-ray group went through (tests / bench)
 };
 
 // =====================================================================================================
@@ -445,17 +447,25 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-// f32 -> (hi, lo) f16 pair with hi + lo == x to ~2^-22 relative.  Rounding toward zero is as good as
-// round-to-nearest for a split (lo absorbs the remainder) and converts two values per instruction
-// (v_cvt_pkrtz_f16_f32); x - float(hi) is a single v_fma_mix_f32 reading the f16 half directly.
+// f32 -> (hi, lo) f16 pair with hi + lo == x to ~2^-22 relative.  hi is rounded to NEAREST (v_cvt_pk_f16_f32, two
+// values per instruction, new in gfx950): for the full 3-term product the rounding mode of hi is irrelevant (lo
+// absorbs the remainder), but a layer evaluated WITHOUT the Whi.Xlo term (TERMS == 2 below) sees |x - hi| as its error:
+// half as large and unbiased with round-to-nearest (tools/precision_study.py: 2.2x less output error than with
+// v_cvt_pkrtz).  x - float(hi) is a single v_fma_mix_f32 reading the f16 half directly.
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ fp16x2 cvt_rtn(float a, float b) {
+    return __builtin_bit_cast(fp16x2, __builtin_convertvector(float2v{a, b}, half2v));
+}
 
 __device__ __forceinline__ void split8(const float (&v)[8], half8 &hi, half8 &lo) {
     unsigned int hw[4], lw[4];
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
-        const fp16x2 hp = __builtin_amdgcn_cvt_pkrtz(v[e], v[e + 1]);
-        const fp16x2 lp = __builtin_amdgcn_cvt_pkrtz(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
+        const fp16x2 hp = cvt_rtn(v[e], v[e + 1]);
+        const fp16x2 lp = cvt_rtn(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
         hw[e / 2] = __builtin_bit_cast(unsigned int, hp);
         lw[e / 2] = __builtin_bit_cast(unsigned int, lp);
     }
@@ -654,7 +664,8 @@ __device__ __forceinline__ void act_fetch(const float *bias, const float *wsig, 
     if constexpr (SIG) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(in.w) : "v"(lds_addr(wsig + 4 * h)), "n"(F * 4));
 }
 
-template <int T, int HS, bool SIG, int STAGE>
+// LO = false: the consumer of this fragment is a 2-term layer (no Whi.Xlo product): only hi is produced
+template <int T, int HS, bool SIG, int STAGE, bool LO = true>
 __device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const ActIn &in, half8 (&bh)[16], half8 (&bl)[16],
                                           float &part, ActRegs &g) {
     constexpr int IB = T / 2, Q = T % 2;
@@ -670,10 +681,11 @@ __device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const ActIn &i
 #pragma unroll
         for (int e = 0; e < 4; e++) g.x[e] = __builtin_fmaf(g.y[e], 1.5f, __builtin_fabsf(g.y[e]));
     } else if constexpr (STAGE == 3) {
-        g.hp[0] = __builtin_amdgcn_cvt_pkrtz(g.x[0], g.x[1]);
-        g.hp[1] = __builtin_amdgcn_cvt_pkrtz(g.x[2], g.x[3]);
+        g.hp[0] = cvt_rtn(g.x[0], g.x[1]);
+        g.hp[1] = cvt_rtn(g.x[2], g.x[3]);
         if constexpr (SIG) part += in.w[0] * g.x[0] + in.w[1] * g.x[1] + in.w[2] * g.x[2] + in.w[3] * g.x[3];
     } else if constexpr (STAGE == 4) {
+        if constexpr (!LO) return;
         // remainder x - float(hi) in one v_fma_mix_f32 per value (reads the f16 half directly)
         const unsigned int p0 = __builtin_bit_cast(unsigned int, g.hp[0]), p1 = __builtin_bit_cast(unsigned int, g.hp[1]);
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[0]) : "v"(p0), "v"(g.x[0]));
@@ -681,10 +693,12 @@ __device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const ActIn &i
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[2]) : "v"(p1), "v"(g.x[2]));
         asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[3]) : "v"(p1), "v"(g.x[3]));
     } else {
-        g.lp[0] = __builtin_amdgcn_cvt_pkrtz(g.y[0], g.y[1]);
-        g.lp[1] = __builtin_amdgcn_cvt_pkrtz(g.y[2], g.y[3]);
         put_pairs<HS>(bh[T], g.hp[0], g.hp[1]);
-        put_pairs<HS>(bl[T], g.lp[0], g.lp[1]);
+        if constexpr (LO) {
+            g.lp[0] = cvt_rtn(g.y[0], g.y[1]);
+            g.lp[1] = cvt_rtn(g.y[2], g.y[3]);
+            put_pairs<HS>(bl[T], g.lp[0], g.lp[1]);
+        }
     }
 }
 
@@ -761,7 +775,11 @@ __device__ __forceinline__ void layer8_fetch(const float *bias, const float *bia
     if constexpr (P::ACT) act_fetch<P::T, P::HS, P::SIG>(P::PEND ? bias_pend : bias, wsig, h, st.in[U & 1]);
 }
 
-template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
+// TERMS = 3: Whi.Xhi + Wlo.Xhi + Whi.Xlo (6 MFMAs per unit);  TERMS = 2: the Whi.Xlo products are dropped (4 MFMAs per
+// unit; the colour layers fc_5 / fc_6, whose error is not amplified by the density head -- DESIGN.md).
+// LO_PEND / LO_OWN: whether the fragments activated in this layer (previous layer's lower half / this layer's upper
+// half) need their lo part, i.e. whether their CONSUMER is a 3-term layer.
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS, bool LO_PEND, bool LO_OWN, int U>
 __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
                                             f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
                                             int h, float &part) {
@@ -777,6 +795,7 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     constexpr int S = P::S, IB = 4 * P::HALF + 2 * (P::REM & 1);
     constexpr int T = P::T, HS = P::HS;
     constexpr bool SIG = P::SIG, ACT = P::ACT;
+    constexpr bool LO = P::PEND ? LO_PEND : LO_OWN;
     ActRegs g;
     half8(&a)[4] = st.ring[U % RD];
     half8(&nx)[4] = st.ring[UN % RD];
@@ -788,13 +807,25 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
     if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
-    if constexpr (ACT) act_stage<T, HS, SIG, K>(acc, in, bh, bl, part, g); \
+    if constexpr (ACT) act_stage<T, HS, SIG, K, LO>(acc, in, bh, bl, part, g); \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DBG & 16) {
         asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(bh[S]), "v"(bl[S]));
         if constexpr (S == 0) { acc[IB] = zero16(); acc[IB + 1] = zero16(); }
         SDN_STAGE(0) SDN_STAGE(1) SDN_STAGE(2) SDN_STAGE(3) SDN_STAGE(4) SDN_STAGE(5)
+    } else if constexpr (TERMS == 2) {
+        // 4 MFMAs: the six activation stages share four gaps (stage 4 is empty and stage 5 a single move when !LO)
+        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], zero16());
+        else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
+        SDN_STAGE(0) SDN_STAGE(1)
+        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], zero16());
+        else acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
+        SDN_STAGE(2)
+        acc[IB] = mfma16(a[1], bh[S], acc[IB]);
+        SDN_STAGE(3)
+        acc[IB + 1] = mfma16(a[3], bh[S], acc[IB + 1]);
+        SDN_STAGE(4) SDN_STAGE(5)
     } else {
         if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], zero16());
         else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
@@ -814,14 +845,14 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
 #undef SDN_STAGE
 }
 
-template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int... Us>
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS, bool LO_PEND, bool LO_OWN, int... Us>
 __device__ __forceinline__ void layer8_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
                                              half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8], const float *bias,
                                              const float *bias_pend, const float *wsig, int h, float &part) {
-    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, acc, bias, bias_pend, wsig, h, part), ...);
+    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN, Us>(lds, r, st, bh, bl, acc, bias, bias_pend, wsig, h, part), ...);
 }
 
-template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN>
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS = 3, bool LO_PEND = true, bool LO_OWN = true>
 __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
                                        const float *bias, const float *bias_pend, const float *wsig, int h, float &part) {
     LayerState st;
@@ -830,8 +861,8 @@ __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half
     layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, 0>(bias, bias_pend, wsig, h, st);
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
-    layer8_units<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh, bl, acc, bias,
-                                                  bias_pend, wsig, h, part);
+    layer8_units<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh,
+                                                                             bl, acc, bias, bias_pend, wsig, h, part);
 }
 
 // Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of the last hidden layer is
@@ -910,7 +941,8 @@ __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], h
     out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, bias_pend, h, part);
 }
 
-template <int DBG>
+// CT = number of split terms of the colour layers fc_5 / fc_6 (3, or 2 = without the Whi.Xlo products)
+template <int DBG, int CT>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -970,6 +1002,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
 
         float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float carry = 0.f, tsum = 0.f;
+        int n_done = 0;
 
         for (int ch = 0; grp_hit && ch < p.nch; ch++) {
             const size_t tc = (size_t)(tile_ok ? tile : 0) * p.nch + ch;
@@ -1048,8 +1081,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             for (int l = 0; l < 5; l++) {
                 const float *bias = cst + C_BETA + l * HID;
                 const float *bias_pend = l == 0 ? bias1 : bias - HID;   // the previous layer's (its lower half is pending)
-                if (l == 2) layer8<DBG, 16, true, false, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
-                else if (l == 3) layer8<DBG, 16, true, true, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                // fc_4's upper half feeds fc_5, fc_5's activations feed fc_5 / fc_6: no lo parts when those are 2-term
+                if (l == 2) layer8<DBG, 16, true, false, true, 3, true, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                else if (l == 3) layer8<DBG, 16, true, true, false, CT, CT == 3, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                else if (CT != 3 && l == 4) layer8<DBG, 16, true, false, false, CT, CT == 3, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
                 else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
             }
             // ---- fc_out_c ------------------------------------------------------------------------------------------
@@ -1110,7 +1145,24 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     v += __shfl_xor(v, 2);
                     if ((rr >> 2) == q) outq[ib][rr & 3] += v;
                 }
+            // ---- early ray termination (north star: wavefront ballots): once the transmittance exp(-carry) of EVERY ray of
+            //      the workgroup's 32 is below eps, the remaining samples can change net_out by at most 2 eps (their weights
+            //      sum to < eps and that mass goes to the sky term instead): skip the group's remaining passes.  The
+            //      decision is a wave ballot combined over the 4 waves, because they share the weight ring / barriers.
+            if (p.term_depth > 0.f && ch + 1 < p.nch) {
+                const bool opaque = !ray_ok || (flag & 1) || carry > p.term_depth;
+                const bool wave_done = __all(opaque);
+                if (lane == 0) flags[wave] = wave_done ? 1 : 0;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const bool grp_done = __builtin_amdgcn_readfirstlane(flags[0] & flags[1] & flags[2] & flags[3]) != 0;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (grp_done) break;
+            }
+            n_done = ch + 1;
         }
+        if (p.passes && threadIdx.x == 0) p.passes[grp] = (uint8_t)n_done;   // passes this group went through (tests / bench)
 
         // ---- blend the sky, store ---------------------------------------------------------------------------------
         tsum += __shfl_xor(tsum, 1);
@@ -1464,10 +1516,14 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
 
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
-                  int32_t n_workgroups, sdn_stream_t stream) {
+                  int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, sdn_stream_t stream) {
     SDN_REQUIRE(feat && dist && label && rayflag && packed && consts && sky_c && net_out, "sdn_field_mlp: null pointer");
     SDN_REQUIRE(n_rays > 0 && num_samples > 0, "sdn_field_mlp: empty frame");
+    SDN_REQUIRE(colour_terms == 2 || colour_terms == 3, "sdn_field_mlp: colour_terms must be 2 or 3");
+    SDN_REQUIRE(term_eps >= 0.f && term_eps < 1.f, "sdn_field_mlp: term_eps must be in [0, 1)");
     MlpParams p;
+    p.term_depth = term_eps > 0.f ? -logf(term_eps) : 0.f;
+    p.passes = passes;
     p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag; p.wpk = (const half8 *)packed;
     p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
     p.R = n_rays; p.ns = num_samples;
@@ -1482,18 +1538,21 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     }();
     switch (dbg) {
 #ifdef SDN_MLP_ABLATION
-        case 1: hipLaunchKernelGGL(mlp_kernel<1>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring DMA
-        case 256: hipLaunchKernelGGL(mlp_kernel<256>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // no input prefetch
-        case 384: hipLaunchKernelGGL(mlp_kernel<384>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
-        case 128: hipLaunchKernelGGL(mlp_kernel<128>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // input-staging timer
-        case 2: hipLaunchKernelGGL(mlp_kernel<2>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring barrier
-        case 3: hipLaunchKernelGGL(mlp_kernel<3>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
-        case 4: hipLaunchKernelGGL(mlp_kernel<4>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no activation VALU
-        case 8: hipLaunchKernelGGL(mlp_kernel<8>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no fragment ds_read
-        case 16: hipLaunchKernelGGL(mlp_kernel<16>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // no MFMA
-        case 28: hipLaunchKernelGGL(mlp_kernel<28>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+        case 1: hipLaunchKernelGGL((mlp_kernel<1, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring DMA
+        case 256: hipLaunchKernelGGL((mlp_kernel<256, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // no input prefetch
+        case 384: hipLaunchKernelGGL((mlp_kernel<384, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+        case 128: hipLaunchKernelGGL((mlp_kernel<128, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // input-staging timer
+        case 2: hipLaunchKernelGGL((mlp_kernel<2, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no ring barrier
+        case 3: hipLaunchKernelGGL((mlp_kernel<3, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+        case 4: hipLaunchKernelGGL((mlp_kernel<4, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no activation VALU
+        case 8: hipLaunchKernelGGL((mlp_kernel<8, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no fragment ds_read
+        case 16: hipLaunchKernelGGL((mlp_kernel<16, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // no MFMA
+        case 28: hipLaunchKernelGGL((mlp_kernel<28, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
 #endif
-        default: hipLaunchKernelGGL(mlp_kernel<0>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+        default:
+            if (colour_terms == 2) hipLaunchKernelGGL((mlp_kernel<0, 2>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL((mlp_kernel<0, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+            break;
     }
     return sdn::check_launch("sdn_field_mlp");
 }

@@ -22,6 +22,13 @@ def _is_init():
     return dist.is_available() and dist.is_initialized()
 
 
+def _scatter_supported():
+    """Whether the scatter + all_gather form is used.  Decided ONCE and IDENTICALLY on every rank from the backend
+    name -- never per call with try/except around a collective: if one rank raised and fell back to broadcast while
+    the others sat in scatter, the job would hang."""
+    return dist.get_backend() in ("nccl", "gloo")
+
+
 def broadcast_large(t, src=0, min_numel=1 << 20):
     """Broadcast tensor `t` (allocated with the right shape/dtype on every rank) from `src`."""
     world = dist.get_world_size()
@@ -29,18 +36,14 @@ def broadcast_large(t, src=0, min_numel=1 << 20):
         return t
     flat = t.reshape(-1)
     n = flat.numel()
-    if n < min_numel or n % world != 0 or not t.is_contiguous():
+    if n < min_numel or n % world != 0 or not t.is_contiguous() or not _scatter_supported():
         dist.broadcast(t, src)
         return t
     chunk = n // world
     rank = dist.get_rank()
     mine = torch.empty(chunk, dtype=t.dtype, device=t.device)
     parts = [flat[i * chunk:(i + 1) * chunk].contiguous() for i in range(world)] if rank == src else None
-    try:
-        dist.scatter(mine, parts, src=src)
-    except (RuntimeError, NotImplementedError):   # a backend without scatter: every rank takes the plain broadcast
-        dist.broadcast(t, src)
-        return t
+    dist.scatter(mine, parts, src=src)
     outs = [torch.empty(chunk, dtype=t.dtype, device=t.device) for _ in range(world)]
     dist.all_gather(outs, mine)
     if rank != src:

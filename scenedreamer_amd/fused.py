@@ -1,6 +1,7 @@
 """Host side of the fused field renderer (csrc/field.hip): per-scene / per-style preparation and the
 per-frame encode -> mlp launches.  PyTorch only provides device memory and the stream."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -34,6 +35,11 @@ def prepare_scene(R):
     capi.check(rc, "sdn_field_collapse_table")
     scales = np.empty(L, np.float32)
     capi.check(lib.sdn_grid_level_scales(L, float(np.float32(R.grid_S)), 16, scales.ctypes.data, None))
+    # the kernel indexes a 1024-entry table with id & 1023; ids the reference's LUT does not cover would raise
+    # there (mc_utils.py:241-246) -- refuse them here instead of mapping them silently
+    vmax = int(R.voxel_t.max())
+    if vmax >= min(R.lut.numel(), 1024) or int(R.voxel_t.min()) < 0:
+        raise RuntimeError(f"scene holds voxel id {vmax}, outside the label table ({R.lut.numel()} entries)")
     lut = torch.full((1024,), 3, dtype=torch.uint8)
     n = min(R.lut.numel(), 1024)
     lut[:n] = R.lut[:n].to(torch.uint8).cpu()
@@ -103,16 +109,38 @@ def encode(R, vid, d2, rd, cam_ori, ns, buf=None):
 FEATURE_BUFFER_BYTES = 32 << 30   # rays are processed in chunks whose encode -> mlp feature buffer stays below this
 
 
+def precision_profile(R):
+    """(colour_terms, term_eps) of the field MLP for this renderer.
+
+    colour_terms: f16 split terms of the colour layers fc_5 / fc_6 (3 = Whi.Xhi + Wlo.Xhi + Whi.Xlo like every other
+    layer; 2 = without Whi.Xlo -- nothing amplifies their error, tools/precision_study.py).
+    term_eps: early ray termination once the transmittance of all 32 rays of a workgroup is below it (0 = off);
+    bounds the change of net_out by 2 * term_eps."""
+    ct = getattr(R, "colour_terms", None)
+    if ct is None:
+        ct = int(os.environ.get("SDN_MLP_COLOUR_TERMS", "3"))
+    eps = getattr(R, "term_eps", None)
+    if eps is None:
+        eps = float(os.environ.get("SDN_TERM_EPS", "0"))
+    return ct, eps
+
+
+def _launch_mlp(R, buf, st, sky_c, net_out, n_rays, ns, passes=None):
+    ct, eps = precision_profile(R)
+    with torch.cuda.device(R.dev):
+        rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
+                                  buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
+                                  sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, ct, eps,
+                                  passes.data_ptr() if passes is not None else None, 0, _stream(R.dev))
+    capi.check(rc, "sdn_field_mlp")
+
+
 def mlp_from(R, buf, sky_c, sky_avg, n_rays, ns):
     """Second half of field_fused for an already encoded ray set (the pipelined trajectory path)."""
     st = R._fused_style or prepare_style(R)
     st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
     net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
-    with torch.cuda.device(R.dev):
-        rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                  buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
-                                  sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, 0, _stream(R.dev))
-    capi.check(rc, "sdn_field_mlp")
+    _launch_mlp(R, buf, st, sky_c, net_out, n_rays, ns)
     return net_out
 
 
@@ -120,7 +148,7 @@ def single_chunk(n_rays, ns):
     return n_rays * (_lib().sdn_field_feat_bytes(32, ns) // 32) <= FEATURE_BUFFER_BYTES
 
 
-def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns):
+def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None):
     """net_out [R,64] for intersections vid [R,M] / d2 [2,R,M] / raydirs rd [R,3].
     Rays are independent, so very large frames (4K x 40 samples = 174 GB of features) go through in ray chunks that
     reuse one feature buffer; the headline frame (6.9 GB) is a single chunk."""
@@ -134,11 +162,7 @@ def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns):
         r1 = min(n_rays, r0 + chunk)
         v, d, r_, s_ = vid[r0:r1].contiguous(), d2[:, r0:r1].contiguous(), rd[r0:r1].contiguous(), sky_c[r0:r1].contiguous()
         buf = encode(R, v, d, r_, cam_ori, ns)
-        with torch.cuda.device(R.dev):
-            rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                      buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
-                                      s_.data_ptr(), net_out[r0:r1].data_ptr(), r1 - r0, ns, 0, _stream(R.dev))
-        capi.check(rc, "sdn_field_mlp")
+        _launch_mlp(R, buf, st, s_, net_out[r0:r1], r1 - r0, ns, passes[r0 // 32:] if passes is not None else None)
     return net_out
 
 
@@ -153,14 +177,17 @@ def time_mlp_kernel(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, reps=5):
     net_out = torch.empty((n, 64), dtype=torch.float32, device=R.dev)
     sky_c = sky_c.contiguous()
 
-    def launch():
-        with torch.cuda.device(R.dev):
-            capi.check(_lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                            buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
-                                            sky_c.data_ptr(), net_out.data_ptr(), n, ns, 0, _stream(R.dev)))
-    ms = _time_ms(launch, reps)
+    ms = _time_ms(lambda: _launch_mlp(R, buf, st, sky_c, net_out, n, ns), reps)
     hit = float((vid[:, 0] != 0).float().mean())
-    return n * ns, ms, hit
+    # samples the kernel actually evaluates: it skips 32-ray groups (4 tiles of 8 consecutive rays) that hit nothing,
+    # and the passes early termination removes
+    g = torch.nn.functional.pad((vid[:, 0] != 0), (0, (-n) % 32)).view(-1, 32).any(dim=1)
+    passes = torch.zeros(g.numel(), dtype=torch.uint8, device=R.dev)
+    _launch_mlp(R, buf, st, sky_c, net_out, n, ns, passes)
+    executed = int(passes.sum(dtype=torch.int64))
+    nch = -(-ns // 4)
+    return n * ns, ms, hit, dict(group_hit_fraction=float(g.float().mean()), evaluated_samples=executed * 128,
+                                 passes_skipped_by_termination=int(g.sum()) * nch - executed)
 
 
 def time_encode_kernel(R, vid, d2, rd, cam_ori, ns, reps=5):

@@ -202,7 +202,13 @@ class Renderer:
 
     # ------------------------------------------------------------------ measurement
     def compute_dtype(self, mode):
-        return "f32" if mode == "unfused" else "f32 (hash grid) + f16x3-split MFMA with f32 accumulate (MLP)"
+        if mode == "unfused":
+            return "f32"
+        from . import fused
+        ct, _ = fused.precision_profile(self)
+        t3 = getattr(self, "cnn_terms3x3", None) or int(os.environ.get("SDN_CNN_TERMS", "1"))
+        return (f"f32 (hash grid) + f16 MFMA with f32 accumulate: field/sky MLP 3-term split"
+                f"{' (colour layers 2-term)' if ct == 2 else ''}, render CNN 1x1 3-term / 3x3 {t3}-term")
 
     def measure_roofline(self, pose, resolution_hw, num_samples, mode, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0):
         """Roofline records, timed with events on the launch stream (PyTorch's current stream).
@@ -237,31 +243,47 @@ class Renderer:
             sky_c = self.sky_features(rd)
             sky_avg = sky_c.mean(dim=0, keepdim=True)
             B, ms_enc, per_sample, kernel = fused.time_encode_kernel(self, vid, d2, rd, cam_ori, num_samples)
-            _, ms_mlp, hit = fused.time_mlp_kernel(self, vid, d2, rd, cam_ori, sky_c, sky_avg, num_samples)
-        traffic = _profiled_traffic()
-        # encode_kernel: its compulsory HBM traffic is the feature write (512 B) + dist/label (5 B) + the ray records
-        # (84 B / ray); the 8-corner gather (4 096 B/sample of the collapsed table, 16 384 B in the reference) is served
-        # by L2 / Infinity Cache.  `achieved` prices the kernel against what it must move through HBM; the
-        # reference-equivalent gather rate (16 404 B/sample) is reported beside it.
-        # features are only written for rays that hit something (ray-level hit fraction; the kernel skips whole 8-ray tiles)
-        hbm_per_sample = 512 * hit + 5 + 84.0 / num_samples
-        ach_g = B * hbm_per_sample / (ms_enc * 1e-3) / 1e9
-        grid = {"bound": "hbm", "kernel": kernel, "achieved": ach_g, "peak": hbm_peak_gbps, "unit": "GB/s",
-                "frac": ach_g / hbm_peak_gbps, "traffic": traffic.get("encode_kernel"), "samples_per_launch": B,
-                "algorithmic_bytes_per_sample": hbm_per_sample, "avg_launch_ms": ms_enc,
-                "reference_equivalent": {"bytes_per_sample": per_sample, "GBps": B * per_sample / (ms_enc * 1e-3) / 1e9},
-                "note": "achieved = compulsory HBM bytes (feature write for rays that hit + aux + ray records) / launch time; traffic = "
-                        "FETCH+WRITE bytes per launch from the PMC profile (profiles/r01_pmc_traffic.json); "
-                        "reference_equivalent prices the same launch at the reference's 16 404 B/sample of gathers, "
-                        "which here hit L2/Infinity Cache (collapsed table: 4 096 B/sample gathered)"}
-        ach_m = B * 754176 / (ms_mlp * 1e-3) / 1e12
-        mlp = {"bound": "mfma", "kernel": "mlp_kernel (f16 MFMA, 3-term split, f32 accumulate)", "achieved": ach_m,
-               "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach_m / mfma_peak_tflops,
-               "traffic": traffic.get("mlp_kernel"), "samples_per_launch": B, "algorithmic_flop_per_sample": 754176,
-               "avg_launch_ms": ms_mlp, "ray_hit_fraction": hit, "issued_over_algorithmic": 3.0,
-               "note": "algorithmic FLOPs = every sample of the frame x 754 176; the kernel issues 3 f16 MFMAs per "
-                       "algorithmic product (hi*hi + lo*hi + hi*lo: plain f16 misses the 1e-3 bound 17x) and skips "
-                       "32-ray groups that hit nothing; traffic = HBM bytes per launch from the PMC profile"}
+            _, ms_mlp, hit, ev = fused.time_mlp_kernel(self, vid, d2, rd, cam_ori, sky_c, sky_avg, num_samples)
+        traffic, traffic_src = _profiled_traffic()
+        ct, eps = fused.precision_profile(self)
+        # ---- grid sampler (encode_kernel).  SURVEY 8(d): effective gather bandwidth = samples x 16 404 B / time.  The
+        # gathers are served on-die (collapsed table: 8 x 32 B per level instead of 32 x 32 B, L2 / Infinity-Cache
+        # hits), so that figure exceeds the HBM peak many times over: HBM does not bound this kernel, the L2-level
+        # gather rate does.  All three rates are reported; `frac` is against the bound that applies (aggregate L2).
+        n_gather = B * hit                                   # samples of rays that hit something: the others issue no gathers
+        eff = B * 16404 / (ms_enc * 1e-3) / 1e9              # SURVEY 8(d) definition, every sample of the frame
+        coll = n_gather * (4096 + 20 + 512) / (ms_enc * 1e-3) / 1e9   # bytes the kernel really moves at L2 level
+        dram = traffic.get("encode_kernel")
+        grid = {"bound": "l2", "kernel": kernel, "achieved": coll, "peak": L2_PEAK_GBPS, "unit": "GB/s",
+                "frac": coll / L2_PEAK_GBPS, "avg_launch_ms": ms_enc, "samples_per_launch": B,
+                "samples_with_gathers": n_gather,
+                "effective_GBps": eff, "effective_bytes_per_sample": 16404, "effective_over_hbm_peak": eff / hbm_peak_gbps,
+                "collapsed_GBps": coll, "collapsed_bytes_per_sample": 4096 + 20 + 512,
+                "dram_GBps_from_profile": (dram / (ms_enc * 1e-3) / 1e9) if dram else None,
+                "dram_frac_of_hbm_peak_from_profile": (dram / (ms_enc * 1e-3) / 1e9 / hbm_peak_gbps) if dram else None,
+                "traffic": dram, "traffic_source": traffic_src,
+                "note": "effective = SURVEY 8(d): samples x 16 404 B (reference's 32-corner 5-D gather) / launch time -- "
+                        "served on-die, hence far above the 8 TB/s HBM peak; collapsed = what this kernel moves at L2 level "
+                        "(8 corners x 32 B x 16 levels + 20 B coords + 512 B feature write, only for rays that hit); "
+                        "dram = FETCH+WRITE bytes of the PMC profile named in traffic_source / launch time (mostly the "
+                        "feature write); peak = aggregate L2 bandwidth (MI355X_MICROARCH.md: 34.5 TB/s)"}
+        # ---- field MLP.  Algorithmic FLOPs are counted on the samples the kernel EVALUATES (it skips 32-ray groups that
+        # hit nothing and the passes early termination removes): samples of skipped groups are not work done.
+        n_eval = ev["evaluated_samples"]
+        ach_m = n_eval * 754176 / (ms_mlp * 1e-3) / 1e12
+        issued = (2208 - (256 if ct == 2 else 0)) / 736.0     # MFMAs per pass / algorithmic (one per product tile)
+        mlp = {"bound": "mfma", "kernel": f"mlp_kernel (f16 MFMA, 3-term split, colour layers {ct}-term, f32 accumulate)",
+               "achieved": ach_m, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach_m / mfma_peak_tflops,
+               "traffic": traffic.get("mlp_kernel"), "traffic_source": traffic_src,
+               "samples_per_launch": B, "samples_evaluated": n_eval, "algorithmic_flop_per_sample": 754176,
+               "avg_launch_ms": ms_mlp, "ray_hit_fraction": hit, "group_hit_fraction": ev["group_hit_fraction"],
+               "early_termination_eps": eps, "passes_skipped_by_termination": ev["passes_skipped_by_termination"],
+               "issued_over_algorithmic": issued, "issued_frac_of_peak": ach_m * issued / mfma_peak_tflops,
+               "achieved_counting_skipped_samples": B * 754176 / (ms_mlp * 1e-3) / 1e12,
+               "note": "achieved = samples evaluated x 754 176 FLOP / launch time (skipped sky groups are not counted as "
+                       "work); the kernel issues `issued_over_algorithmic` f16 MFMAs per algorithmic product (hi*hi + "
+                       "lo*hi + hi*lo: plain f16 misses the 1e-3 bound 17x); traffic = HBM bytes per launch from the "
+                       "PMC profile named in traffic_source (a separate rocprofv3 --pmc run, not this process)"}
         return mlp, grid
 
     # ------------------------------------------------------------------ row bands (tile-parallel single frame)
@@ -309,7 +331,7 @@ class Renderer:
             if cnn_mode == "mfma":
                 if getattr(self, "_mfma_cnn", None) is None:
                     from .cnn import MfmaCNN
-                    self._mfma_cnn = MfmaCNN(self)
+                    self._mfma_cnn = MfmaCNN(self, getattr(self, "cnn_terms3x3", None))
                 img = self._mfma_cnn(net_out)
             else:
                 img = self.render_cnn(net_out)
@@ -383,7 +405,7 @@ class Renderer:
             if cnn_mode == "mfma":
                 if getattr(self, "_mfma_cnn", None) is None:
                     from .cnn import MfmaCNN
-                    self._mfma_cnn = MfmaCNN(self)
+                    self._mfma_cnn = MfmaCNN(self, getattr(self, "cnn_terms3x3", None))
                 img = self._mfma_cnn(net_out)
             else:
                 img = self.render_cnn(net_out)
@@ -453,7 +475,7 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
             net_out = fused.mlp_from(self, buf, sky_c, sky_avg, n, num_samples).view(1, Hp, Wp, 64)
             if getattr(self, "_mfma_cnn", None) is None:
                 from .cnn import MfmaCNN
-                self._mfma_cnn = MfmaCNN(self)
+                self._mfma_cnn = MfmaCNN(self, getattr(self, "cnn_terms3x3", None))
             img = self._mfma_cnn(net_out)
             c = crop - o
             yield img[:, :, c:-c, c:-c] if c else img
@@ -464,15 +486,25 @@ Renderer.render_frames = _render_frames
 CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (conv2a, conv2b, conv3a, conv3b)
 
 
+L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md: 4 MiB per XCD, ~34.5 TB/s aggregate
+PMC_PROFILE = "r02_pmc_traffic.json"
+
+
 def _profiled_traffic():
-    """HBM bytes per launch from the committed PMC profile (bench.py cannot run rocprofv3 on itself)."""
+    """(HBM bytes per launch by kernel, source label) from the committed PMC profile: bench.py cannot run rocprofv3 on
+    itself, so `traffic` in the roofline records is NOT measured in the bench process -- the label says so."""
     import json
-    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(p) as f:
-            return {k: v["traffic"] for k, v in json.load(f)["per_launch_bytes"].items()}
-    except (OSError, KeyError, ValueError):
-        return {}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in (PMC_PROFILE, "r01_pmc_traffic.json"):
+        try:
+            with open(os.path.join(root, "profiles", name)) as f:
+                d = json.load(f)
+            return ({k: v["traffic"] for k, v in d["per_launch_bytes"].items()},
+                    f"profiles/{name} (rocprofv3 --pmc passes of tools/frame_once.py, build {d.get('commit', 'unrecorded')}; "
+                    f"not measured in this run)")
+        except (OSError, KeyError, ValueError):
+            continue
+    return {}, None
 
 
 def _time_ms(fn, reps=5):
