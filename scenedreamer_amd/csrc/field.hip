@@ -1149,6 +1149,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             //      the workgroup's 32 is below eps, the remaining samples can change net_out by at most 2 eps (their weights
             //      sum to < eps and that mass goes to the sky term instead): skip the group's remaining passes.  The
             //      decision is a wave ballot combined over the 4 waves, because they share the weight ring / barriers.
+            n_done = ch + 1;
             if (p.term_depth > 0.f && ch + 1 < p.nch) {
                 const bool opaque = !ray_ok || (flag & 1) || carry > p.term_depth;
                 const bool wave_done = __all(opaque);
@@ -1160,7 +1161,6 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 __builtin_amdgcn_s_barrier();
                 if (grp_done) break;
             }
-            n_done = ch + 1;
         }
         if (p.passes && threadIdx.x == 0) p.passes[grp] = (uint8_t)n_done;   // passes this group went through (tests / bench)
 

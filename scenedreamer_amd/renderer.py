@@ -201,6 +201,14 @@ class Renderer:
         return torch.tanh(cv(y, "conv4", 0))
 
     # ------------------------------------------------------------------ measurement
+    def set_precision(self, cnn_terms3x3=None, colour_terms=None, term_eps=None):
+        """Precision profile of the MFMA kernels (None = the default of the environment / library):
+        cnn_terms3x3: f16 product terms of the four 3x3 convolutions, 1 (default) or 3 (cnn.py);
+        colour_terms: split terms of the colour layers fc_5 / fc_6, 3 (default) or 2 (fused.precision_profile);
+        term_eps: early ray termination threshold on the transmittance, 0 = off (default)."""
+        self.cnn_terms3x3, self.colour_terms, self.term_eps = cnn_terms3x3, colour_terms, term_eps
+        self._mfma_cnn = None
+
     def compute_dtype(self, mode):
         if mode == "unfused":
             return "f32"

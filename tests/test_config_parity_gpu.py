@@ -73,20 +73,29 @@ def test_config3_tiles_against_oracle(big, lut):
     _check_tiles(big, lut, (1080, 1920), 40, 12, lambda nh, nw: [(0, 0), (nh // 2, nw // 2)], 135)
 
 
-def test_row_bands_equal_full_frame(big):
+@pytest.mark.parametrize("terms3x3,bound", [(3, 1e-6), (1, 5e-4)])
+def test_row_bands_equal_full_frame(big, terms3x3, bound):
     """The tile-parallel single-frame path (BASELINE config 5) on ONE GPU: band_prepare / band_finish over 3 row bands
-    with the frame-wide sky mean stitched as dist.render_frame_tile_parallel does it == render_frame, to 1e-6
-    (the only difference is the order of the sky-mean partial sums)."""
+    with the frame-wide sky mean stitched as dist.render_frame_tile_parallel does it == render_frame.  The only
+    difference between the two is the order of the sky-mean partial sums (~1e-7 on net_out): with the 3-term CNN the
+    images agree to 1e-6; with the default 1-term 3x3 layers such a perturbation can flip the f16 rounding of an
+    activation, so agreement is to the CNN's own error level (a few 1e-4), not bitwise."""
     R, scene, poses, w, _ = big
     hw, ns = (540, 960), 24
     pose = poses[9]
-    full = R.render_frame(pose, hw, ns, mode="fused")
-    bounds = [0, 173, 361, 540]
-    hds = [R.band_prepare(pose, hw, bounds[i], bounds[i + 1], mode="fused") for i in range(3)]
-    tot = sum(h["sky_sum"] for h in hds)
-    cnt = sum(h["sky_cnt"] for h in hds)
-    assert cnt == (hw[0] + R.pad) * (hw[1] + R.pad)
-    sky_avg = (tot / cnt).to(torch.float32)
-    img = torch.cat([R.band_finish(h, sky_avg, ns) for h in hds], dim=2)
+    R.set_precision(cnn_terms3x3=terms3x3)
+    try:
+        full = R.render_frame(pose, hw, ns, mode="fused")
+        bounds = [0, 173, 361, 540]
+        hds = [R.band_prepare(pose, hw, bounds[i], bounds[i + 1], mode="fused") for i in range(3)]
+        tot = sum(h["sky_sum"] for h in hds)
+        cnt = sum(h["sky_cnt"] for h in hds)
+        assert cnt == (hw[0] + R.pad) * (hw[1] + R.pad)
+        sky_avg = (tot / cnt).to(torch.float32)
+        img = torch.cat([R.band_finish(h, sky_avg, ns) for h in hds], dim=2)
+    finally:
+        R.set_precision()
     assert img.shape == full.shape
-    assert float((img - full).abs().max()) < 1e-6
+    d = float((img - full).abs().max())
+    print(f"row bands vs full frame, terms3x3={terms3x3}: max abs diff {d:.2e}")
+    assert d < bound

@@ -237,3 +237,25 @@ def test_frame_writer_roundtrip(tmp_path):
         np.testing.assert_array_equal(np.asarray(Image.open(os.path.join(tmp_path, files[1]))), ref)
     else:
         np.testing.assert_array_equal(np.load(os.path.join(tmp_path, files[1])), ref)
+
+
+def test_mp4_writer_roundtrip(tmp_path):
+    """FrameWriter(video_path=...): the reference's per-frame `fout.append_data(rgb)` (scenedreamer.py:560, :631) as a
+    Motion-JPEG MP4 written by scenedreamer_amd/mp4.py; box structure, frame count, fps and pixels are read back."""
+    from scenedreamer_amd.mp4 import read_frames
+    from scenedreamer_amd.output import FrameWriter, to_uint8_hwc
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 48), torch.linspace(-1, 1, 64), indexing="ij")
+    frames = [torch.stack([torch.sin(3 * xx + k), torch.cos(2 * yy - k), xx * yy])[None] for k in range(7)]
+    w = FrameWriter(str(tmp_path / "png"), fmt="png", video_path=str(tmp_path / "out.mp4"), fps=10)
+    for i, f in enumerate(frames):
+        w.submit(f, i)
+    w.close()
+    assert w.frames_done == 7 and len(os.listdir(tmp_path / "png")) == 7
+    fps, got = read_frames(str(tmp_path / "out.mp4"))
+    assert fps == 10 and len(got) == 7
+    for f, g in zip(frames, got):
+        ref = to_uint8_hwc(f).numpy().astype(np.int32)
+        assert g.shape == ref.shape
+        assert np.abs(g.astype(np.int32) - ref).mean() < 2.0          # JPEG quality 92, 4:4:4
+    raw = open(tmp_path / "out.mp4", "rb").read()
+    assert raw[4:8] == b"ftyp" and b"moov" in raw and b"co64" in raw
