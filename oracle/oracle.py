@@ -147,6 +147,32 @@ def grid_encode_fwd(inputs, embeddings, offsets, S, H, calc_grad_inputs=False, g
     return (out, dy_dx) if calc_grad_inputs else out
 
 
+def round_half(x):
+    """float32 -> nearest-even half precision value, returned as float32 (oracle's own rounding routine)."""
+    lib().oracle_round_half.restype = ctypes.c_float
+    return np.float32(lib().oracle_round_half(ctypes.c_float(float(x))))
+
+
+def grid_encode_bwd_f16(grad, inputs, embeddings_shape, offsets, S, H, dy_dx=None, gridtype=0, align_corners=False):
+    """Oracle of _gridencoder.grid_encode_backward with half tensors (gridencoder.cu:296-304, :317-343).
+    grad / dy_dx: float16 arrays.  Returns (grad_embeddings f32 = sum of the half-rounded contributions in double,
+    grad_inputs f16 = the reference's sequential half accumulation, exact)."""
+    g = np.ascontiguousarray(np.asarray(grad, np.float16).astype(np.float32))
+    inputs = _f32(inputs)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    L, B, C = g.shape
+    D = inputs.shape[1]
+    gg = np.zeros(embeddings_shape, np.float32)
+    calc = dy_dx is not None
+    dd = np.ascontiguousarray(np.asarray(dy_dx, np.float16).astype(np.float32)) if calc else None
+    gi = np.zeros((B, D), np.float32) if calc else None
+    lib().oracle_grid_encode_bwd_f16(_p(g), _p(inputs), _p(offsets), _p(gg), ctypes.c_uint32(B), ctypes.c_uint32(D),
+                                     ctypes.c_uint32(C), ctypes.c_uint32(L), ctypes.c_float(S), ctypes.c_uint32(H),
+                                     ctypes.c_int(int(calc)), _p(dd) if calc else None, _p(gi) if calc else None,
+                                     ctypes.c_uint32(gridtype), ctypes.c_int(int(align_corners)))
+    return gg, (gi.astype(np.float16) if calc else None)
+
+
 def grid_encode_bwd(grad, inputs, embeddings_shape, offsets, S, H, dy_dx=None, gridtype=0, align_corners=False):
     """Oracle of _gridencoder.grid_encode_backward (f32).  grad [L,B,C] -> (grad_embeddings, grad_inputs|None)."""
     grad, inputs = _f32(grad), _f32(inputs)

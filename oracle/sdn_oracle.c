@@ -362,6 +362,92 @@ ORACLE_API void oracle_grid_encode_bwd(const float *grad_all, const float *input
     }
 }
 
+/* ---- f16 variant of the backward pass (gridencoder.cu:296-304, :317-343 with scalar_t = at::Half) -------------
+ * gcc 11 has no _Float16 on x86: round-to-nearest-even to half precision by hand.                                */
+static float f16r(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = u & 0x80000000u;
+    uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return x;                         /* inf / nan */
+    if (a >= 0x477ff000u) {                                 /* rounds to >= 65520 -> inf */
+        a = 0x7f800000u;
+    } else if (a < 0x38800000u) {                           /* below the smallest normal half 2^-14: subnormal grid 2^-24 */
+        float ax;
+        memcpy(&ax, &a, 4);
+        const float q = ax * 16777216.0f;                   /* / 2^-24, exact */
+        const float r = nearbyintf(q);                      /* default rounding mode: to nearest even */
+        ax = r * (1.0f / 16777216.0f);
+        memcpy(&a, &ax, 4);
+    } else {
+        const uint32_t lsb = (a >> 13) & 1u;
+        a += 0x00000fffu + lsb;
+        a &= 0xffffe000u;
+    }
+    a |= sign;
+    float r;
+    memcpy(&r, &a, 4);
+    return r;
+}
+
+ORACLE_API float oracle_round_half(float x) { return f16r(x); }
+
+/* grad / dy_dx hold half values (as floats).  grad_grid_all (+=): every contribution rounded to half like the
+ * reference's (__half)(w * grad), then summed in double -- the reference adds them with half-precision atomics in
+ * nondeterministic order, so comparisons use a tolerance.  grad_inputs: the reference's sequential half accumulation
+ * (scalar_t result; result += grad * dy_dx), reproduced exactly.                                                  */
+ORACLE_API void oracle_grid_encode_bwd_f16(const float *grad_all, const float *inputs, const int32_t *offsets,
+                                           float *grad_grid_all, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                           float S, uint32_t H, int calc_grad_inputs, const float *dy_dx,
+                                           float *grad_inputs, uint32_t gridtype, int align_corners) {
+    size_t total = (size_t)(uint32_t)offsets[L] * C;
+    double *acc = (double *)calloc(total, sizeof(double));
+    for (uint32_t level = 0; level < L; level++) {
+        double *gg = acc + (size_t)(uint32_t)offsets[level] * C;
+        const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+        const float scale = exp2f(level * S) * H - 1.0f;
+        const uint32_t resolution = (uint32_t)ceil(scale) + 1;
+        for (uint32_t b = 0; b < B; b++) {
+            const float *in = inputs + (size_t)b * D;
+            const float *grad = grad_all + (size_t)level * B * C + (size_t)b * C;
+            int oob = 0;
+            for (uint32_t d = 0; d < D; d++)
+                if (in[d] < 0 || in[d] > 1) oob = 1;
+            if (oob) continue;
+            float pos[8];
+            uint32_t pos_grid[8];
+            for (uint32_t d = 0; d < D; d++) {
+                pos[d] = in[d] * scale + (align_corners ? 0.0f : 0.5f);
+                pos_grid[d] = (uint32_t)floorf(pos[d]);
+                pos[d] -= (float)pos_grid[d];
+            }
+            for (uint32_t idx = 0; idx < (1u << D); idx++) {
+                float w = 1;
+                uint32_t pgl[8];
+                for (uint32_t d = 0; d < D; d++) {
+                    if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pgl[d] = pos_grid[d]; }
+                    else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
+                }
+                uint32_t index = get_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
+                for (uint32_t ch = 0; ch < C; ch++) gg[index + ch] += (double)f16r(w * grad[ch]);
+            }
+        }
+    }
+    for (size_t i = 0; i < total; i++) grad_grid_all[i] += (float)acc[i];
+    free(acc);
+    if (calc_grad_inputs) {
+        for (uint32_t t = 0; t < B * D; t++) {
+            uint32_t b = t / D, d = t - b * D;
+            const float *dd = dy_dx + (size_t)b * L * D * C;
+            float result = 0;
+            for (uint32_t l = 0; l < L; l++)
+                for (uint32_t ch = 0; ch < C; ch++)
+                    result = f16r(result + f16r(grad_all[(size_t)l * B * C + (size_t)b * C + ch] * dd[l * D * C + d * C + ch]));
+            grad_inputs[t] = result;
+        }
+    }
+}
+
 ORACLE_API void oracle_set_num_threads(int n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

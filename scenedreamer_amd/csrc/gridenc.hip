@@ -23,6 +23,8 @@
 //     samples; the reference's uint32 offsets overflow there, gridencoder.cu:87-96).
 #include <hip/hip_fp16.h>
 
+#include <type_traits>
+
 #include "sdn_common.h"
 
 namespace {
@@ -299,10 +301,28 @@ __global__ __launch_bounds__(FWD_THREADS) void grid_fwd_kernel(const float *__re
 // hardware atomics a full 32 B row per lane keeps the L2 atomic units fed with
 // adjacent addresses).  Order of accumulation is nondeterministic, as in the
 // reference.
-template <uint32_t D, uint32_t C>
-__global__ __launch_bounds__(256) void grid_bwd_kernel(const float *__restrict__ grad, const float *__restrict__ inputs,
+// f16 (gridencoder.cu:296-304): the two contributions of a channel pair are rounded to half ((__half)(w * g)) and
+// added with ONE packed atomic (global_atomic_pk_add_f16), i.e. the table gradient is accumulated in half precision
+// like the reference's; C == 1 (where the reference's at::Half atomicAdd is an empty stub) goes through a CAS on
+// the aligned 32-bit word.
+__device__ __forceinline__ void atomic_add_half(__half *dst, float v) {
+    unsigned int *word = reinterpret_cast<unsigned int *>(reinterpret_cast<uintptr_t>(dst) & ~(uintptr_t)3);
+    const bool upper = (reinterpret_cast<uintptr_t>(dst) & 2) != 0;
+    unsigned int old = *word, assumed;
+    do {
+        assumed = old;
+        const unsigned short cur = upper ? (unsigned short)(assumed >> 16) : (unsigned short)(assumed & 0xffffu);
+        const __half sum = __float2half(__half2float(__ushort_as_half(cur)) + v);
+        const unsigned int bits = __half_as_ushort(sum);
+        const unsigned int repl = upper ? ((assumed & 0x0000ffffu) | (bits << 16)) : ((assumed & 0xffff0000u) | bits);
+        old = atomicCAS(word, assumed, repl);
+    } while (old != assumed);
+}
+
+template <typename T, uint32_t D, uint32_t C>
+__global__ __launch_bounds__(256) void grid_bwd_kernel(const T *__restrict__ grad, const float *__restrict__ inputs,
                                                        const int32_t *__restrict__ offsets,
-                                                       float *__restrict__ grad_grid, uint32_t B, uint32_t L, float S,
+                                                       T *__restrict__ grad_grid, uint32_t B, uint32_t L, float S,
                                                        uint32_t H, uint32_t gridtype, bool align_corners,
                                                        const GridLevels lv) {
     const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
@@ -311,7 +331,7 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const float *__restrict__
     const uint32_t level = blockIdx.y;
     grad_grid += (uint64_t)(uint32_t)offsets[level] * C;
     const float *in = inputs + b * D;
-    const float *g = grad + ((uint64_t)level * B + b) * C;
+    const T *g = grad + ((uint64_t)level * B + b) * C;
 
     float x[D];
 #pragma unroll
@@ -349,28 +369,50 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const float *__restrict__
             }
         }
         const uint32_t row = grid_row<D>(pgl, gridtype, dim_stride, hashmap_size);
-        float *dst = grad_grid + (uint64_t)row * C;
+        T *dst = grad_grid + (uint64_t)row * C;
+        if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(dst + c, w * gc[c]);
+            for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(dst + c, w * gc[c]);
+        } else if constexpr (C % 2 == 0) {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c += 2)
+                unsafeAtomicAdd(reinterpret_cast<__half2 *>(dst + c), __halves2half2(__float2half(w * gc[c]), __float2half(w * gc[c + 1])));
+        } else {
+            atomic_add_half(dst, __half2float(__float2half(w * gc[0])));
+        }
     }
 }
 
 // grad_inputs[b,d] = sum_{l,c} grad[l,b,c] * dy_dx[b,l,d,c]   (:317-343)
-template <uint32_t D, uint32_t C>
-__global__ __launch_bounds__(256) void grid_input_bwd_kernel(const float *__restrict__ grad,
-                                                             const float *__restrict__ dy_dx,
-                                                             float *__restrict__ grad_inputs, uint32_t B, uint32_t L) {
+// T = __half: `scalar_t result` of the reference is a half and every product / sum rounds to half (:331-340); the same
+// sequence is evaluated here, so the result is bit-identical to a sequential half evaluation.
+template <typename T, uint32_t D, uint32_t C>
+__global__ __launch_bounds__(256) void grid_input_bwd_kernel(const T *__restrict__ grad,
+                                                             const T *__restrict__ dy_dx,
+                                                             T *__restrict__ grad_inputs, uint32_t B, uint32_t L) {
     const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (uint64_t)B * D) return;
     const uint64_t b = t / D;
     const uint32_t d = (uint32_t)(t - b * D);
-    const float *dd = dy_dx + b * L * (uint64_t)(D * C);
-    float r = 0.f;
-    for (uint32_t l = 0; l < L; l++) {
+    const T *dd = dy_dx + b * L * (uint64_t)(D * C);
+    if constexpr (std::is_same<T, float>::value) {
+        float r = 0.f;
+        for (uint32_t l = 0; l < L; l++) {
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) r += grad[((uint64_t)l * B + b) * C + c] * dd[(l * D + d) * C + c];
+            for (uint32_t c = 0; c < C; c++) r += grad[((uint64_t)l * B + b) * C + c] * dd[(l * D + d) * C + c];
+        }
+        grad_inputs[t] = r;
+    } else {
+        __half r = __float2half(0.f);
+        for (uint32_t l = 0; l < L; l++) {
+#pragma unroll
+            for (uint32_t c = 0; c < C; c++) {
+                const __half prod = __float2half(__half2float(grad[((uint64_t)l * B + b) * C + c]) * __half2float(dd[(l * D + d) * C + c]));
+                r = __float2half(__half2float(r) + __half2float(prod));
+            }
+        }
+        grad_inputs[t] = r;
     }
-    grad_inputs[t] = r;
 }
 
 template <typename T, uint32_t D>
@@ -401,31 +443,42 @@ int launch_fwd(const float *inputs, const T *emb, const int32_t *offsets, T *out
     }
 }
 
-template <uint32_t D, uint32_t C>
-int launch_bwd_dc(const float *grad, const float *inputs, const int32_t *offsets, float *gg, uint32_t B, uint32_t L,
-                  float S, uint32_t H, bool cg, const float *dy_dx, float *gi, uint32_t gridtype, bool ac,
+template <typename T, uint32_t D, uint32_t C>
+int launch_bwd_dc(const T *grad, const float *inputs, const int32_t *offsets, T *gg, uint32_t B, uint32_t L,
+                  float S, uint32_t H, bool cg, const T *dy_dx, T *gi, uint32_t gridtype, bool ac,
                   hipStream_t st) {
     const dim3 grid(sdn::div_up<uint32_t>(B, 256), L, 1);
-    hipLaunchKernelGGL((grid_bwd_kernel<D, C>), grid, dim3(256), 0, st, grad, inputs, offsets, gg, B, L, S, H, gridtype, ac,
+    hipLaunchKernelGGL((grid_bwd_kernel<T, D, C>), grid, dim3(256), 0, st, grad, inputs, offsets, gg, B, L, S, H, gridtype, ac,
                        make_levels(L, S, H));
     if (cg) {
         const uint64_t n = (uint64_t)B * D;
-        hipLaunchKernelGGL((grid_input_bwd_kernel<D, C>), dim3((uint32_t)sdn::div_up<uint64_t>(n, 256)), dim3(256), 0,
+        hipLaunchKernelGGL((grid_input_bwd_kernel<T, D, C>), dim3((uint32_t)sdn::div_up<uint64_t>(n, 256)), dim3(256), 0,
                            st, grad, dy_dx, gi, B, L);
     }
     return sdn::check_launch("sdn_grid_encode_bwd");
 }
 
-template <uint32_t D>
-int launch_bwd_d(const float *grad, const float *inputs, const int32_t *offsets, float *gg, uint32_t B, uint32_t C,
-                 uint32_t L, float S, uint32_t H, bool cg, const float *dy_dx, float *gi, uint32_t gridtype, bool ac,
+template <typename T, uint32_t D>
+int launch_bwd_d(const T *grad, const float *inputs, const int32_t *offsets, T *gg, uint32_t B, uint32_t C,
+                 uint32_t L, float S, uint32_t H, bool cg, const T *dy_dx, T *gi, uint32_t gridtype, bool ac,
                  hipStream_t st) {
     switch (C) {
-        case 1: return launch_bwd_dc<D, 1>(grad, inputs, offsets, gg, B, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
-        case 2: return launch_bwd_dc<D, 2>(grad, inputs, offsets, gg, B, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
-        case 4: return launch_bwd_dc<D, 4>(grad, inputs, offsets, gg, B, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
-        case 8: return launch_bwd_dc<D, 8>(grad, inputs, offsets, gg, B, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
+        case 1: return launch_bwd_dc<T, D, 1>(grad, inputs, offsets, gg, B, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
+        case 2: return launch_bwd_dc<T, D, 2>(grad, inputs, offsets, gg, B, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
+        case 4: return launch_bwd_dc<T, D, 4>(grad, inputs, offsets, gg, B, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
+        case 8: return launch_bwd_dc<T, D, 8>(grad, inputs, offsets, gg, B, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
         default: return sdn::fail(SDN_ERR_UNSUPPORTED, "GridEncoding: C must be 1, 2, 4, or 8.");
+    }
+}
+
+template <typename T>
+int launch_bwd(const T *grad, const float *inputs, const int32_t *offsets, T *gg, uint32_t B, uint32_t D, uint32_t C,
+               uint32_t L, float S, uint32_t H, bool cg, const T *dy_dx, T *gi, uint32_t gridtype, bool ac, hipStream_t st) {
+    switch (D) {
+        case 2: return launch_bwd_d<T, 2>(grad, inputs, offsets, gg, B, C, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
+        case 3: return launch_bwd_d<T, 3>(grad, inputs, offsets, gg, B, C, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
+        case 4: return launch_bwd_d<T, 4>(grad, inputs, offsets, gg, B, C, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
+        default: return launch_bwd_d<T, 5>(grad, inputs, offsets, gg, B, C, L, S, H, cg, dy_dx, gi, gridtype, ac, st);
     }
 }
 
@@ -471,21 +524,18 @@ extern "C" int sdn_grid_encode_bwd(const void *grad, const float *inputs, const 
     if (D < 2 || D > 5) return sdn::fail(SDN_ERR_UNSUPPORTED, "GridEncoding: D must be 2, 3, 4, or 5.");
     if (!(C == 1 || C == 2 || C == 4 || C == 8))
         return sdn::fail(SDN_ERR_UNSUPPORTED, "GridEncoding: C must be 1, 2, 4, or 8.");
-    if (emb_dtype != SDN_F32)
-        return sdn::fail(SDN_ERR_UNSUPPORTED, "sdn_grid_encode_bwd: only f32 gradients are implemented");
+    if (emb_dtype != SDN_F32 && emb_dtype != SDN_F16)
+        return sdn::fail(SDN_ERR_UNSUPPORTED, "sdn_grid_encode_bwd: gradients must be f32 or f16");
     SDN_REQUIRE(gridtype <= 1, "sdn_grid_encode_bwd: gridtype must be 0 (hash) or 1 (tiled)");
     SDN_REQUIRE(L >= 1 && L <= 65535, "sdn_grid_encode_bwd: L out of range");
     if (B == 0) return SDN_OK;
     SDN_REQUIRE(grad && inputs && offsets && grad_embeddings, "sdn_grid_encode_bwd: null pointer");
     SDN_REQUIRE(!calc_grad_inputs || (dy_dx && grad_inputs), "sdn_grid_encode_bwd: dy_dx/grad_inputs required");
     hipStream_t st = (hipStream_t)stream;
-    const float *g = (const float *)grad;
-    float *gg = (float *)grad_embeddings;
     const bool cg = calc_grad_inputs != 0, ac = align_corners != 0;
-    switch (D) {
-        case 2: return launch_bwd_d<2>(g, inputs, offsets, gg, B, C, L, S, H, cg, (const float *)dy_dx, (float *)grad_inputs, gridtype, ac, st);
-        case 3: return launch_bwd_d<3>(g, inputs, offsets, gg, B, C, L, S, H, cg, (const float *)dy_dx, (float *)grad_inputs, gridtype, ac, st);
-        case 4: return launch_bwd_d<4>(g, inputs, offsets, gg, B, C, L, S, H, cg, (const float *)dy_dx, (float *)grad_inputs, gridtype, ac, st);
-        default: return launch_bwd_d<5>(g, inputs, offsets, gg, B, C, L, S, H, cg, (const float *)dy_dx, (float *)grad_inputs, gridtype, ac, st);
-    }
+    if (emb_dtype == SDN_F16)
+        return launch_bwd<__half>((const __half *)grad, inputs, offsets, (__half *)grad_embeddings, B, D, C, L, S, H, cg,
+                                  (const __half *)dy_dx, (__half *)grad_inputs, gridtype, ac, st);
+    return launch_bwd<float>((const float *)grad, inputs, offsets, (float *)grad_embeddings, B, D, C, L, S, H, cg,
+                             (const float *)dy_dx, (float *)grad_inputs, gridtype, ac, st);
 }

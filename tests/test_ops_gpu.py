@@ -247,6 +247,33 @@ def test_grid_backward(ops, oracle):
         np.testing.assert_allclose(gi.cpu().numpy(), rgi, rtol=1e-4, atol=5e-3)
 
 
+def test_grid_backward_half(ops, oracle):
+    """f16 tables / gradients (gridencoder.cu:296-304: contributions rounded to half, packed half2 atomics; :317-343:
+    the input gradient accumulated sequentially in half).  grad_inputs must equal the oracle's sequential half
+    evaluation BIT FOR BIT; the table gradient is a half-precision sum in arbitrary order: tolerance ~ a few half
+    ulps of the largest entry.  C = 1 (odd channel count: the reference's at::Half atomicAdd is an empty stub) goes
+    through the CAS path and is checked the same way."""
+    for D, C in ((3, 2), (5, 8), (2, 1), (4, 4)):
+        offs, emb, x, S = _grid_case(D, C, 4, 9, 4, 1.5, 0, False, 500, 3 * D + C)
+        L = offs.size - 1
+        B = x.shape[0]
+        rng = np.random.default_rng(9)
+        grad = rng.standard_normal((L, B, C)).astype(np.float16)
+        xd, od = torch.from_numpy(x).cuda(), torch.from_numpy(offs).cuda()
+        ed = torch.from_numpy(emb).half().cuda()
+        out = torch.empty(L, B, C, device="cuda", dtype=torch.half)
+        dy = torch.empty(B, L * D * C, device="cuda", dtype=torch.half)
+        ops.grid_encode_forward(xd, ed, od, out, B, D, C, L, S, 4, True, dy, 0, False)
+        gg = torch.zeros_like(ed)
+        gi = torch.zeros(B, D, device="cuda", dtype=torch.half)
+        ops.grid_encode_backward(torch.from_numpy(grad).cuda(), xd, ed, od, gg, B, D, C, L, S, 4, True, dy, gi, 0, False)
+        rgg, rgi = oracle.grid_encode_bwd_f16(grad, x, emb.shape, offs, S, 4, dy.cpu().numpy())
+        np.testing.assert_array_equal(gi.cpu().numpy().view(np.uint16), rgi.view(np.uint16))
+        scale = float(np.abs(rgg).max())
+        np.testing.assert_allclose(gg.float().cpu().numpy(), rgg, rtol=0, atol=1e-2 * scale)
+        assert float(np.abs(rgg).max()) > 0.5
+
+
 def test_grid_rejects_unsupported(ops):
     x = torch.rand(8, 3, device="cuda")
     offs = torch.tensor([0, 64], dtype=torch.int32, device="cuda")

@@ -66,7 +66,7 @@ def test_reference_call_transcript_through_the_shims(scene256, weights_full):
             offsets = torch.from_numpy(g[f"c{i}_offsets"]).cuda()
             outputs = torch.empty(d[3]["shape"], dtype=torch.float32, device="cuda")
             dy_dx = torch.empty(d[11]["shape"], dtype=torch.float32, device="cuda")     # the reference's placeholder [1]
-            scal = [_rebuild(x, None, None) for x in d]
+            scal = [None if x["kind"] == "tensor" else _rebuild(x, None, None) for x in d]
             fn(inputs, emb, offsets, outputs, scal[4], scal[5], scal[6], scal[7], scal[8], scal[9], scal[10], dy_dx,
                scal[12], scal[13])
             rows = g[f"c{i}_rows"]
