@@ -103,7 +103,7 @@ def cpu_baseline(args, weights, scene, z, genc):
     from scenedreamer_amd.camera import tile_grid
     from scenedreamer_amd.renderer import load_label_lut
     lut = load_label_lut()["lut"]
-    vox = scene.voxel_t.cpu().numpy()
+    vox = scene.voxel_t.cpu().numpy()          # (a compact scene expands to the reference's int32 ids here)
     # z / global_enc: the per-trajectory codes (computed once per style / scene, not per frame) as the renderer holds them
     pose = camera.eval_camera_poses(scene, maxstep=40)[8]
     p = (pose[0].numpy(), pose[1].numpy(), pose[2].numpy(), pose[3])
@@ -172,8 +172,12 @@ def main():
     scene = synth.make_scene(args.scene_size, 3407, device=dev) if rank == 0 or world == 1 else None
     weights = synth.make_weights(0) if rank == 0 or world == 1 else None
     style = synth.make_style(8888) if rank == 0 or world == 1 else None
+    bstats = {}
     if world > 1:
-        scene, weights, style = sdist.broadcast_state(scene, weights, style, dev, src=0)
+        t_b = time.time()
+        scene, weights, style = sdist.broadcast_state(scene, weights, style, dev, src=0, stats=bstats)
+        torch.cuda.synchronize()
+        bstats["broadcast_s"] = time.time() - t_b
     R = Renderer(weights, scene, dev)
     R.set_style(style)
     maxstep = args.cam_maxstep
@@ -287,7 +291,7 @@ def main():
                                      "'minimal' evaluates the field MLP and the CNN on the 4-px apron that can reach a kept "
                                      "pixel -- the image is bit-identical (tests/test_render_gpu.py, test_fullsize_gpu.py)"},
             "frame_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "delivered_frames_per_s_uint8_host": delivered_fps,
-            "stage_ms": stage_ms, "setup_s": setup_s, f"ms_per_step_apron_{other}": other_ms,
+            "stage_ms": stage_ms, "setup_s": setup_s, "broadcast": bstats or None, f"ms_per_step_apron_{other}": other_ms,
             "roofline": roof, "roofline_grid_sampler": roof_grid,
         }
         if world == 1 and not args.no_cpu_baseline:

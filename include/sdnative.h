@@ -69,6 +69,39 @@ size_t sdn_rvip_occupancy_bytes(const int64_t *dims);
 int sdn_rvip_build_occupancy(const int32_t *vox, const int64_t *dims, const int64_t *strides, uint8_t *occupancy,
                              sdn_stream_t stream);
 
+/* Compact volume (no reference counterpart): the same ray marcher over a uint8 volume of PALETTE INDICES
+ * (0 = empty) with palette256 dev int32[256] (palette256[0] == 0) -- a world holds ~20 distinct block ids, so the
+ * volume is 4x smaller than the reference's int32 ids (PCGVoxelGenerator.voxel_t, pcg_gen.py:119,173) while
+ * out_voxel_id carries the same int32 block ids: outputs are bit-identical to sdn_rvip on the expanded volume. */
+int sdn_rvip_u8(const uint8_t *vox, const int32_t *palette256, const int64_t *dims, const int64_t *strides,
+                const float *cam_ori, const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
+                const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id, float *out_depth,
+                float *out_raydirs, sdn_stream_t stream);
+int sdn_rvip_build_occupancy_u8(const uint8_t *vox, const int64_t *dims, const int64_t *strides, uint8_t *occupancy,
+                                sdn_stream_t stream);
+/* int32 ids (any strides) -> palette indices, out dev u8 [dims] contiguous.  id2idx dev u8[n_ids]: index of every id
+ * (id2idx[0] == 0); *bad_flag (dev int32, zeroed by the caller) is set when the volume holds an id outside the table
+ * or one the palette does not contain. */
+int sdn_volume_compact(const int32_t *vox, const int64_t *dims, const int64_t *strides, const uint8_t *id2idx, int n_ids,
+                       uint8_t *out, int32_t *bad_flag, sdn_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Scene ingestion on the GPU: PCGVoxelGenerator.next_world (imaginaire/model_utils/pcg_gen.py:119-164) writing the
+ * compact volume directly.  volume dev u8 [sample_height, S0, S1], zeroed by the caller.
+ *   sdn_scene_columns      terrain shell (:121-128): cells h .. h+pad_num of every column (clipped to the volume) =
+ *                          column_idx (dev u8 [S0,S1], palette index of the column's biome block); height_map dev i16.
+ *   sdn_scene_paste_trees  (:134-159) trees_hxym dev int32 [n_trees,4] = (h, x, y, model); models dev u8 (palette
+ *                          indices, 0 = empty) concatenated, model m at model_offsets[m] with extent model_dims[3m..];
+ *                          a model cell is written only where the world is still empty.  Trees of ONE call must not
+ *                          overlap each other: the caller issues overlapping trees in successive calls, in tree order
+ *                          (an earlier tree keeps the cell, like the reference's sequential loop).
+ *   sdn_scene_column_tops  (:162-164) top dev int32 [S0,S1]: highest non-empty cell of every column, 0 if none. */
+int sdn_scene_columns(const int16_t *height_map, const uint8_t *column_idx, int sample_height, int S0, int S1, int pad_num,
+                      uint8_t *volume, sdn_stream_t stream);
+int sdn_scene_paste_trees(uint8_t *volume, int sample_height, int S0, int S1, const int32_t *trees_hxym, int n_trees,
+                          const uint8_t *models, const int32_t *model_offsets, const int32_t *model_dims, sdn_stream_t stream);
+int sdn_scene_column_tops(const uint8_t *volume, int sample_height, int S0, int S1, int32_t *top, sdn_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * voxlib.positional_encoding / positional_encoding_backward
  *   replaces positional_encoding_cuda / positional_encoding_backward_cuda

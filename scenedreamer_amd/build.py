@@ -27,6 +27,7 @@ SOURCES = {
     # no SLP vectorisation: hipcc pairs fp32 ops into v_pk_* and pays for it with v_mov shuffles and spills in the MLP kernel
     "field.hip": ["-fno-slp-vectorize"] + (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
     "cnn.hip": (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
+    "scene.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
 

@@ -73,8 +73,16 @@ _ORBITS = {
 }
 
 
+def _ground_extent(scene):
+    """(size(1), size(2)) of the scene volume (camctl.py:15) without expanding a compact scene's int32 view."""
+    v = getattr(scene, "voxel_u8", None)
+    if v is None:
+        v = scene.voxel_t
+    return int(v.shape[1]), int(v.shape[2])
+
+
 def _orbit_poses(scene, maxstep, cam_ang, decay, spec):
-    sy, sz = scene.voxel_t.size(1), scene.voxel_t.size(2)
+    sy, sz = _ground_extent(scene)
     circle = torch.linspace(0, 2 * np.pi, steps=maxstep)
     size = min(sy, sz) / 2
     shift = size * 0.2
@@ -119,7 +127,7 @@ def eval_camera_poses(scene, maxstep=40, pattern=0, cam_ang=72, smooth_decay_mul
     what makes frame sharding across GPUs trivial."""
     if smooth_decay_multiplier is None:
         smooth_decay_multiplier = 150 / maxstep
-    sy, sz = scene.voxel_t.size(1), scene.voxel_t.size(2)
+    sy, sz = _ground_extent(scene)
     if pattern in _ORBITS:
         return _orbit_poses(scene, maxstep, cam_ang, 0.2 * smooth_decay_multiplier, _ORBITS[pattern])
     circle = torch.linspace(0, 2 * np.pi, steps=maxstep)

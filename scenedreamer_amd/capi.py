@@ -32,6 +32,12 @@ _SIGNATURES = {
     "sdn_rvip": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sdn_rvip_occupancy_bytes": (ctypes.c_size_t, [c_p]),
     "sdn_rvip_build_occupancy": (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    "sdn_rvip_u8": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
+    "sdn_rvip_build_occupancy_u8": (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    "sdn_volume_compact": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "sdn_scene_columns": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "sdn_scene_paste_trees": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "sdn_scene_column_tops": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "sdn_posenc_fwd": (c_i, [c_p, c_p, c_i64, c_i64, c_i, c_i, c_p]),
     "sdn_posenc_bwd": (c_i, [c_p, c_p, c_p, c_i64, c_i64, c_i, c_i, c_p]),
     "sdn_grid_encode_fwd": (c_i, [c_p, c_p, c_i, c_p, c_p, c_u, c_u, c_u, c_u, c_f, c_u, c_i, c_p, c_u, c_i, c_p]),

@@ -18,6 +18,10 @@
 // order -- found with the same float expressions the walk evaluates, hence bit-identical outputs (tests compare
 // against the oracle and against the kernel without the grid).
 //
+// Compact volume: the same kernel instantiated for a uint8 volume of PALETTE INDICES (index 0 = empty)
+// with an int32 palette of at most 256 block ids -- a SceneDreamer world uses ~20 distinct ids -- so the volume the
+// rays walk (and the ranks receive) is 4x smaller while voxel_id comes out as the very same int32 block ids.
+//
 // MI355X mapping: one wavefront (64 lanes) owns an 8x8 pixel tile so that the
 // lanes' rays stay spatially coherent while they march (neighbouring rays read
 // neighbouring cache lines of the volume).  Four tiles (4 waves) share a
@@ -42,6 +46,7 @@ struct RvipParams {
     int32_t tiles_x, tiles_y, n_tiles;
     const uint8_t *occ;   // [nb0][nb1][nb2] 1 = block holds a non-empty cell; nullptr = no skipping
     int32_t nb1, nb2;
+    const int32_t *palette;   // uint8 volumes: block id of palette index i (palette[0] == 0); unused for int32 volumes
 };
 
 constexpr int BS0 = 3, BS1 = 4, BS2 = 4;   // log2 of the occupancy block extent per axis (axis 0 is the short, vertical one)
@@ -92,10 +97,11 @@ __device__ __forceinline__ float first_crossing(int cell, float ori, float dir) 
     return HUGE_VALF;
 }
 
+template <typename V>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__restrict__ out_id,
                                                                   float *__restrict__ out_depth,
                                                                   float *__restrict__ out_dirs,
-                                                                  const int32_t *__restrict__ vox,
+                                                                  const V *__restrict__ vox,
                                                                   const RvipParams p) {
     // ---- tile assignment (XCD-aware, bijective) ------------------------------
     const int wave = threadIdx.x >> 6;
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
                 continue;  // :198 outside the volume but heading towards it
             blk = vox[i0 * p.vs[0] + i1 * p.vs[1] + i2 * p.vs[2]];
             if (blk == 0) continue;
+            if constexpr (sizeof(V) == 1) blk = p.palette[blk];
             t = tnow;
             te = (t0 <= t1 && t0 <= t2) ? t0 : (t1 <= t2 ? t1 : t2);  // :222-228
             break;
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
 }
 
 // one workgroup per occupancy block: does any cell of the block (clipped to the volume) hold a non-zero id?
-__global__ __launch_bounds__(256) void occupancy_kernel(uint8_t *__restrict__ occ, const int32_t *__restrict__ vox, int vd0, int vd1,
+template <typename V>
+__global__ __launch_bounds__(256) void occupancy_kernel(uint8_t *__restrict__ occ, const V *__restrict__ vox, int vd0, int vd1,
                                                         int vd2, int64_t vs0, int64_t vs1, int64_t vs2, int nb1, int nb2) {
     const int b = blockIdx.x;
     const int b2 = b % nb2, b1 = (b / nb2) % nb1, b0 = b / (nb2 * nb1);
@@ -249,24 +257,35 @@ extern "C" size_t sdn_rvip_occupancy_bytes(const int64_t *dims) {
            sdn::div_up<int64_t>(dims[2], 1 << BS2);
 }
 
-extern "C" int sdn_rvip_build_occupancy(const int32_t *vox, const int64_t *dims, const int64_t *strides, uint8_t *occ,
-                                        sdn_stream_t stream) {
+template <typename V>
+static int build_occupancy(const V *vox, const int64_t *dims, const int64_t *strides, uint8_t *occ, sdn_stream_t stream) {
     SDN_REQUIRE(vox && dims && strides && occ, "sdn_rvip_build_occupancy: null argument");
     SDN_REQUIRE(dims[0] > 0 && dims[1] > 0 && dims[2] > 0 && dims[0] < (1ll << 31) && dims[1] < (1ll << 31) &&
                     dims[2] < (1ll << 31),
                 "sdn_rvip_build_occupancy: bad voxel dims");
     const size_t n = sdn_rvip_occupancy_bytes(dims);
     SDN_REQUIRE(n < (1ull << 31), "sdn_rvip_build_occupancy: volume too large");
-    hipLaunchKernelGGL(occupancy_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, occ, vox, (int)dims[0], (int)dims[1],
+    hipLaunchKernelGGL(occupancy_kernel<V>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, occ, vox, (int)dims[0], (int)dims[1],
                        (int)dims[2], strides[0], strides[1], strides[2], (int)sdn::div_up<int64_t>(dims[1], 1 << BS1),
                        (int)sdn::div_up<int64_t>(dims[2], 1 << BS2));
     return sdn::check_launch("sdn_rvip_build_occupancy");
 }
 
-extern "C" int sdn_rvip(const int32_t *vox, const int64_t *dims, const int64_t *strides, const float *cam_ori,
-                        const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
-                        const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id,
-                        float *out_depth, float *out_raydirs, sdn_stream_t stream) {
+extern "C" int sdn_rvip_build_occupancy(const int32_t *vox, const int64_t *dims, const int64_t *strides, uint8_t *occ,
+                                        sdn_stream_t stream) {
+    return build_occupancy<int32_t>(vox, dims, strides, occ, stream);
+}
+
+extern "C" int sdn_rvip_build_occupancy_u8(const uint8_t *vox, const int64_t *dims, const int64_t *strides, uint8_t *occ,
+                                           sdn_stream_t stream) {
+    return build_occupancy<uint8_t>(vox, dims, strides, occ, stream);
+}
+
+template <typename V>
+static int rvip_launch(const V *vox, const int32_t *palette, const int64_t *dims, const int64_t *strides, const float *cam_ori,
+                       const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
+                       const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id,
+                       float *out_depth, float *out_raydirs, sdn_stream_t stream) {
     SDN_REQUIRE(vox && dims && strides && cam_ori && cam_dir && cam_up && cam_c && img_dims,
                 "sdn_rvip: null argument");
     SDN_REQUIRE(out_voxel_id && out_depth && out_raydirs, "sdn_rvip: null output");
@@ -308,11 +327,29 @@ extern "C" int sdn_rvip(const int32_t *vox, const int64_t *dims, const int64_t *
     p.tiles_y = sdn::div_up(p.H, TILE);
     p.n_tiles = p.tiles_x * p.tiles_y;
     p.occ = occupancy;
+    p.palette = palette;
     p.nb1 = (int32_t)sdn::div_up<int64_t>(dims[1], 1 << BS1);
     p.nb2 = (int32_t)sdn::div_up<int64_t>(dims[2], 1 << BS2);
 
     const int n_wg = sdn::div_up(p.n_tiles, WAVES_PER_WG);
-    hipLaunchKernelGGL(rvip_kernel, dim3(n_wg), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, out_voxel_id,
+    hipLaunchKernelGGL(rvip_kernel<V>, dim3(n_wg), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, out_voxel_id,
                        out_depth, out_raydirs, vox, p);
     return sdn::check_launch("sdn_rvip");
+}
+
+extern "C" int sdn_rvip(const int32_t *vox, const int64_t *dims, const int64_t *strides, const float *cam_ori,
+                        const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
+                        const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id,
+                        float *out_depth, float *out_raydirs, sdn_stream_t stream) {
+    return rvip_launch<int32_t>(vox, nullptr, dims, strides, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples,
+                                occupancy, out_voxel_id, out_depth, out_raydirs, stream);
+}
+
+extern "C" int sdn_rvip_u8(const uint8_t *vox, const int32_t *palette256, const int64_t *dims, const int64_t *strides,
+                           const float *cam_ori, const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
+                           const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id,
+                           float *out_depth, float *out_raydirs, sdn_stream_t stream) {
+    SDN_REQUIRE(palette256, "sdn_rvip_u8: null palette");
+    return rvip_launch<uint8_t>(vox, palette256, dims, strides, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples,
+                                occupancy, out_voxel_id, out_depth, out_raydirs, stream);
 }

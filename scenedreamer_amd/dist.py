@@ -87,27 +87,54 @@ def broadcast_tensor_dict(d, dev, src=0, verify=True):
     return out
 
 
-def broadcast_state(scene, weights, style, dev, src=0):
-    """Rank `src` holds (scene, weights dict of ndarrays, style); everyone gets equivalent objects on `dev`."""
+def broadcast_state(scene, weights, style, dev, src=0, compact=True, stats=None):
+    """Rank `src` holds (scene, weights dict of ndarrays, style); everyone gets equivalent objects on `dev`.
+
+    compact=True: the scene volume travels as uint8 palette indices + an int32[256] palette (scene.py: 0.8 GB instead of
+    the 3.3 GB int32 volume of a 2048^2 world) and the receivers keep it in that form (Renderer walks it directly).
+    A scene with more than 255 distinct block ids, or one on the CPU (gloo tests), is sent as int32.
+    `stats` (optional dict) receives {"scene_volume_bytes": bytes of the volume as sent}."""
     from .synth import Scene
     rank = dist.get_rank()
     tensors = {}
     if rank == src:
         tensors.update({"w:" + k: torch.as_tensor(np.asarray(v)) for k, v in weights.items()})
-        tensors["s:voxel_t"] = scene.voxel_t
+        u8 = getattr(scene, "voxel_u8", None)
+        if u8 is None and compact and scene.voxel_t.is_cuda:
+            from . import scene as sc_mod
+            try:
+                u8, pal = sc_mod.compact(scene.voxel_t)
+            except RuntimeError:            # more than 255 distinct ids: int32 it is
+                u8 = None
+        elif u8 is not None:
+            pal = scene.palette
+        if u8 is not None:
+            tensors["s:voxel_u8"] = u8
+            tensors["s:palette"] = pal
+        else:
+            tensors["s:voxel_t"] = scene.voxel_t
         tensors["s:heightmap"] = scene.heightmap.to(torch.int64)
         tensors["s:current_height_map"] = scene.current_height_map
         tensors["s:current_semantic_map"] = scene.current_semantic_map
         tensors["s:trans_mat"] = scene.trans_mat
         tensors["z:style"] = torch.as_tensor(np.asarray(style))
     got = broadcast_tensor_dict(tensors, dev, src)
-    sc = Scene()
-    sc.voxel_t = got["s:voxel_t"]
+    if "s:voxel_u8" in got:
+        from .scene import CompactScene
+        sc = CompactScene()
+        sc.voxel_u8, sc.palette = got["s:voxel_u8"], got["s:palette"]
+        vol = sc.voxel_u8
+    else:
+        sc = Scene()
+        sc.voxel_t = got["s:voxel_t"]
+        vol = sc.voxel_t
+    if stats is not None:
+        stats["scene_volume_bytes"] = vol.numel() * vol.element_size()
     sc.heightmap = got["s:heightmap"].cpu()
     sc.current_height_map = got["s:current_height_map"]
     sc.current_semantic_map = got["s:current_semantic_map"]
     sc.trans_mat = got["s:trans_mat"].cpu()
-    sc.sample_size = int(sc.voxel_t.shape[1])
+    sc.sample_size = int(vol.shape[1])
     w = {k[2:]: v for k, v in got.items() if k.startswith("w:")}
     return sc, w, got["z:style"].cpu().numpy()
 

@@ -37,14 +37,14 @@ def prepare_scene(R):
     capi.check(lib.sdn_grid_level_scales(L, float(np.float32(R.grid_S)), 16, scales.ctypes.data, None))
     # the kernel indexes a 1024-entry table with id & 1023; ids the reference's LUT does not cover would raise
     # there (mc_utils.py:241-246) -- refuse them here instead of mapping them silently
-    vmax = int(R.voxel_t.max())
-    if vmax >= min(R.lut.numel(), 1024) or int(R.voxel_t.min()) < 0:
+    vmax = R.max_block_id
+    if vmax >= min(R.lut.numel(), 1024):
         raise RuntimeError(f"scene holds voxel id {vmax}, outside the label table ({R.lut.numel()} entries)")
     lut = torch.full((1024,), 3, dtype=torch.uint8)
     n = min(R.lut.numel(), 1024)
     lut[:n] = R.lut[:n].to(torch.uint8).cpu()
     R._fused_scene = dict(table3=table3, T=T, genc=genc, scales=torch.from_numpy(scales).to(R.dev),
-                          lut=lut.to(R.dev), dims=np.asarray([float(v) for v in R.voxel_t.shape], np.float32))
+                          lut=lut.to(R.dev), dims=np.asarray([float(v) for v in R.voxel_dims], np.float32))
     return R._fused_scene
 
 

@@ -48,23 +48,30 @@ def voxel_occupancy(in_voxel):
         return cached[1]
     lib = capi.lib()
     dims, strides = _l3(*in_voxel.shape), _l3(*in_voxel.stride())
+    build = lib.sdn_rvip_build_occupancy_u8 if in_voxel.dtype == torch.uint8 else lib.sdn_rvip_build_occupancy
     with torch.cuda.device(in_voxel.device):
         occ = torch.empty(lib.sdn_rvip_occupancy_bytes(dims), dtype=torch.uint8, device=in_voxel.device)
-        capi.check(lib.sdn_rvip_build_occupancy(in_voxel.data_ptr(), dims, strides, occ.data_ptr(), _stream(in_voxel)),
-                   "sdn_rvip_build_occupancy")
+        capi.check(build(in_voxel.data_ptr(), dims, strides, occ.data_ptr(), _stream(in_voxel)), "sdn_rvip_build_occupancy")
     in_voxel._sdn_occupancy = (tag, occ)
     return occ
 
 
 def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples,
-                                       accelerate=True):
+                                       accelerate=True, palette=None):
     """voxlib.ray_voxel_intersection_perspective (ray_voxel_intersection.cu:253-325).
 
     Returns [voxel_id i32[H,W,M,1], depth2 f32[2,H,W,M,1], raydirs f32[H,W,1,3]] on in_voxel's device.
     `accelerate` (not in the reference signature) only selects exact empty-space skipping; results are identical.
+    `palette` (not in the reference signature): with a uint8 `in_voxel` of palette indices and an int32[256] palette
+    on the same device the compact volume is walked (scene.py); voxel_id still holds the int32 block ids.
     """
     _require(isinstance(in_voxel, torch.Tensor) and in_voxel.is_cuda, "in_voxel must be a CUDA tensor")
-    _require(in_voxel.dtype == torch.int32, "in_voxel must be int32")
+    if palette is not None:
+        _require(in_voxel.dtype == torch.uint8, "in_voxel must be uint8 when a palette is given")
+        _require(isinstance(palette, torch.Tensor) and palette.is_cuda and palette.dtype == torch.int32 and
+                 palette.numel() == 256 and palette.is_contiguous(), "palette must be a contiguous CUDA int32[256] tensor")
+    else:
+        _require(in_voxel.dtype == torch.int32, "in_voxel must be int32")
     _require(in_voxel.dim() == 3, "in_voxel must be 3-D")
     _require(len(img_dims) == 2, "img_dims must have 2 entries")
     H, W, M = int(img_dims[0]), int(img_dims[1]), int(max_samples)
@@ -77,11 +84,13 @@ def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f
         if H * W * M == 0:
             return [voxel_id, depth2, raydirs]
         occ = voxel_occupancy(in_voxel) if accelerate and in_voxel.numel() > 0 else None
-        rc = capi.lib().sdn_rvip(
-            in_voxel.data_ptr(), _l3(*in_voxel.shape), _l3(*in_voxel.stride()),
-            _host3(cam_ori, "cam_ori"), _host3(cam_dir, "cam_dir"), _host3(cam_up, "cam_up"),
-            cam_f, _f2(float(cam_c[0]), float(cam_c[1])), _i2(H, W), M, occ.data_ptr() if occ is not None else None,
-            voxel_id.data_ptr(), depth2.data_ptr(), raydirs.data_ptr(), _stream(in_voxel))
+        tail = (_host3(cam_ori, "cam_ori"), _host3(cam_dir, "cam_dir"), _host3(cam_up, "cam_up"),
+                cam_f, _f2(float(cam_c[0]), float(cam_c[1])), _i2(H, W), M, occ.data_ptr() if occ is not None else None,
+                voxel_id.data_ptr(), depth2.data_ptr(), raydirs.data_ptr(), _stream(in_voxel))
+        if palette is not None:
+            rc = capi.lib().sdn_rvip_u8(in_voxel.data_ptr(), palette.data_ptr(), _l3(*in_voxel.shape), _l3(*in_voxel.stride()), *tail)
+        else:
+            rc = capi.lib().sdn_rvip(in_voxel.data_ptr(), _l3(*in_voxel.shape), _l3(*in_voxel.stride()), *tail)
     capi.check(rc, "sdn_rvip")
     return [voxel_id, depth2, raydirs]
 

@@ -62,9 +62,21 @@ class Renderer:
     # ------------------------------------------------------------------ once per scene / style
     def set_scene(self, scene):
         self.scene = scene
-        self.voxel_t = scene.voxel_t.to(self.dev)
-        if self.voxel_t.is_cuda:
-            ops.voxel_occupancy(self.voxel_t)   # built here, on the caller's stream, before any side-stream ray casting
+        # compact scenes (scene.CompactScene: uint8 palette indices + int32 palette, 4x smaller) are walked as they are;
+        # the reference's int32 volume otherwise.  `volume` is what the ray marcher gets, `voxel_dims` its extent.
+        self.palette = None
+        if getattr(scene, "voxel_u8", None) is not None:
+            self.volume = scene.voxel_u8.to(self.dev)
+            self.palette = scene.palette.to(self.dev).contiguous()
+            self.max_block_id = int(self.palette.max())
+        else:
+            self.volume = scene.voxel_t.to(self.dev)
+            self.max_block_id = int(self.volume.max()) if self.volume.numel() else 0
+            if self.volume.numel() and int(self.volume.min()) < 0:
+                raise RuntimeError("negative block id in the scene volume")
+        self.voxel_dims = tuple(int(v) for v in self.volume.shape)
+        if self.volume.is_cuda:
+            ops.voxel_occupancy(self.volume)   # built here, on the caller's stream, before any side-stream ray casting
         w = self.w
         with torch.no_grad():  # ConditionalHashGrid.forward, layers.py:40-55
             h = _lrelu(F.conv2d(scene.current_height_map.to(self.dev), w["world_encoder.hconv_head.weight"],
@@ -115,9 +127,14 @@ class Renderer:
     def cast_rays(self, pose, resolution_hw):
         cam_ori, cam_dir, cam_up, cam_f = pose
         f, c, cam_res = frame_intrinsics(cam_f, resolution_hw, self.pad)
-        vid, d2, rd = ops.ray_voxel_intersection_perspective(self.voxel_t, cam_ori, cam_dir, cam_up, f, c, cam_res,
-                                                             self.M)
+        vid, d2, rd = ops.ray_voxel_intersection_perspective(self.volume, cam_ori, cam_dir, cam_up, f, c, cam_res,
+                                                             self.M, palette=self.palette)
         return vid, d2, rd, cam_res
+
+    @property
+    def voxel_t(self):
+        """The int32 block-id volume (expanded on demand for a compact scene)."""
+        return self.volume if self.palette is None else self.scene.voxel_t
 
     def sky_features(self, raydirs):
         """sky_net(PE(raydirs)) for every ray: [R,3] -> [R,64] (scenedreamer.py:368-370, gancraft_base.py:150-169)."""
@@ -153,7 +170,7 @@ class Renderer:
         depth = torch.where(torch.isnan(depth) | torch.isinf(depth), torch.zeros_like(depth), depth)
         wc = raydirs[:, None, :] * depth[:, :, None] + cam_ori[None, None, :]
         lab = torch.gather(self.lut[voxel_id.long()], 1, idx)
-        delim = torch.tensor([float(v) for v in self.voxel_t.shape], device=self.dev)
+        delim = torch.tensor([float(v) for v in self.voxel_dims], device=self.dev)
         n = wc / delim * 2 - 1
         x5 = torch.cat([n, self.global_enc[:, None, :].expand(n.shape[0], n.shape[1], 2)], dim=-1)
         x5 = ((x5 + 1) / 2).reshape(-1, 5).contiguous()           # GridEncoder.forward, grid.py:144
@@ -231,7 +248,7 @@ class Renderer:
                 depth, _, _ = self.place_samples(d2.view(2, R, self.M)[:, :n], num_samples)
                 depth = torch.nan_to_num(depth, nan=0.0, posinf=0.0, neginf=0.0)
                 wc = rd.view(R, 3)[:n, None, :] * depth[:, :, None] + cam_ori
-                delim = torch.tensor([float(v) for v in self.voxel_t.shape], device=self.dev)
+                delim = torch.tensor([float(v) for v in self.voxel_dims], device=self.dev)
                 x5 = torch.cat([wc / delim * 2 - 1, self.global_enc[:, None, :].expand(n, num_samples, 2)], dim=-1)
                 x5 = ((x5 + 1) / 2).reshape(-1, 5).contiguous()
                 B = x5.shape[0]
@@ -305,8 +322,8 @@ class Renderer:
         f, c, cam_res = frame_intrinsics(cam_f, resolution_hw, self.pad)
         p0, p1 = row0, row1 + self.pad
         # same rays as the full frame: ndc_y = c0 - row_global = (c0 - p0) - row_local, exact in float32
-        vid, d2, rd = ops.ray_voxel_intersection_perspective(self.voxel_t, cam_ori, cam_dir, cam_up, f, [c[0] - p0, c[1]],
-                                                             [p1 - p0, cam_res[1]], self.M)
+        vid, d2, rd = ops.ray_voxel_intersection_perspective(self.volume, cam_ori, cam_dir, cam_up, f, [c[0] - p0, c[1]],
+                                                             [p1 - p0, cam_res[1]], self.M, palette=self.palette)
         Wp = cam_res[1]
         n = (p1 - p0) * Wp
         vid, d2, rd = vid.view(n, self.M), d2.view(2, n, self.M), rd.view(n, 3)
