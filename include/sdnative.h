@@ -171,13 +171,22 @@ int sdn_field_collapse_table(const float *embeddings, const int32_t *offsets_hos
 int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const float *wc, void *packed,
                            sdn_stream_t stream);
 /* voxel_id dev i32 [R,M]; depth2 dev f32 [2,R,M]; raydirs dev f32 [R,3]; lut1024 dev u8 [1024] block id ->
- * reduced label (ignore already mapped to dirt); scales_dev f32 [16]; lin_dev f32 [num_samples+1] =
- * linspace(0,1,num_samples+3)[1:-1]; outputs: feat, dist, label (aux_elems each), rayflag u8 [R] */
+ * reduced label (ignore already mapped to dirt); scales_dev f32 [16]; outputs: feat, dist, label (aux_elems each),
+ * rayflag u8 [R].  Sample placement = mc_utils.sample_depth_batched(nsamples = num_samples + 1, use_box_boundaries =
+ * False): deterministic (inference) with u_dev = NULL and lin_dev f32 [num_samples+1] = linspace(0,1,num_samples+3)[1:-1];
+ * stochastic / stratified (training, mc_utils.py:121-125) with u_dev f32 [R, num_samples+1] = the caller's torch.rand draw
+ * and lin_dev = linspace(0,1,num_samples+2)[:-1]. */
 int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
-                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, int32_t n_rays,
-                     int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
+                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
+                     int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
                      float *dist, uint8_t *label, uint8_t *rayflag, sdn_stream_t stream);
+/* mc_utils.sample_depth_batched (imaginaire/model_utils/gancraft/mc_utils.py:82-151, use_box_boundaries = False) as an op:
+ * depth2 dev f32 [2,R,M] -> rand_depth, new_dists dev f32 [R, n_points-1], idx dev i64 [R, n_points-1] (raw values: NaN
+ * depths of rays without a hit are left for the caller to zero, scenedreamer.py:350-352).  lin_dev / u_dev as above with
+ * n_points = nsamples of the reference call. */
+int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_dev, int32_t n_rays, int32_t max_blocks,
+                     int32_t n_points, float sample_depth, float *rand_depth, float *new_dists, int64_t *idx, sdn_stream_t stream);
 /* sky_c dev f32 [R,64] = sky_net output per ray; net_out dev f32 [R,64]; n_workgroups <= 0 -> one per CU.
  * colour_terms: f16 split terms of the colour layers fc_5 / fc_6: 3 (like every other layer) or 2 (without Whi.Xlo).
  * term_eps: early ray termination -- a 32-ray group stops sampling once the transmittance of all its rays is below

@@ -67,16 +67,22 @@ def cumsum_exclusive(t, dim):
     return c
 
 
-def sample_depth_batched(depth2, nsamples, sample_depth):
-    """mc_utils.py:82-151 with deterministic=True, use_box_boundaries=False."""
+def sample_depth_batched(depth2, nsamples, sample_depth, rand=None):
+    """mc_utils.py:82-151 with use_box_boundaries=False; deterministic=True unless `rand` [bs,dim0,dim1,nsamples,1] (what
+    the reference draws with torch.rand at :121) is given: then the stochastic stratified branch :121-124."""
     bs, dim0, dim1 = depth2.size(0), depth2.size(2), depth2.size(3)
     dists = depth2[:, 1] - depth2[:, 0]
     dists[torch.isnan(dists)] = 0
     accu_depth = torch.cumsum(dists, dim=-2)
     total_depth = accu_depth[..., [-1], :]
     total_depth = torch.clamp(total_depth, None, sample_depth)
-    rand_samples = torch.empty([bs, dim0, dim1, nsamples, 1], dtype=total_depth.dtype)
-    rand_samples[..., :, 0] = torch.linspace(0, 1, nsamples + 2)[1:-1]
+    if rand is None:
+        rand_samples = torch.empty([bs, dim0, dim1, nsamples, 1], dtype=total_depth.dtype)
+        rand_samples[..., :, 0] = torch.linspace(0, 1, nsamples + 2)[1:-1]
+    else:
+        rand_samples = torch.as_tensor(rand, dtype=total_depth.dtype).clone()
+        rand_samples = rand_samples / nsamples
+        rand_samples[..., :, 0] += torch.linspace(0, 1, nsamples + 1)[:-1]
     rand_samples = rand_samples * total_depth
     rand_samples, _ = torch.sort(rand_samples, dim=-2, descending=False)
     midpoints = (rand_samples[..., 1:, :] + rand_samples[..., :-1, :]) / 2

@@ -91,7 +91,8 @@ struct EncParams {
     float ori[3], delim[3];
     float sample_depth, dists_scale;
     int32_t genc_oob;          // global_enc outside [0,1] after mapping: every feature is zero
-    const float *lin;          // dev [ns+1]  linspace(0,1,ns+3)[1:-1] (torch.linspace on the host side)
+    const float *lin;          // dev [ns+1]  deterministic: linspace(0,1,ns+3)[1:-1]; stochastic: linspace(0,1,ns+2)[:-1]
+    const float *u;            // dev [R][ns+1] uniform randoms of the training-time stratified sampling, or nullptr
     const float *scales;       // dev [16]    per-level scale, exp2f(l*S)*H-1 evaluated on the host
 };
 
@@ -224,9 +225,21 @@ struct RayBoxes {
 struct Placed {
     float depth, dist;
     int idx;
+    float raw_depth;   // heads + midpoints before the NaN / inf -> 0 replacement
+    int raw_idx;       // #{accu < mid} before clamping to M - 1
 };
 
-__device__ __forceinline__ Placed place_sample(const RayBoxes &rb, int M, const float *lin, int sidx, float sample_depth) {
+// Position of stratified point i in [0,1) (mc_utils.py:116-125): deterministic -> lin[i]; stochastic (training)
+// -> rand / nsamples + linspace(0, 1, nsamples + 1)[i], `u` being the caller's torch.rand draw for this ray.
+__device__ __forceinline__ float strat_pos(const float *lin, const float *u, int n_points, int i) {
+#pragma clang fp contract(off)
+    if (u == nullptr) return lin[i];
+    const float q = u[i] / (float)n_points;
+    return q + lin[i];
+}
+
+__device__ __forceinline__ Placed place_sample(const RayBoxes &rb, int M, const float *lin, const float *u, int n_points, int sidx,
+                                               float sample_depth) {
 #pragma clang fp contract(off)
     // mc_utils.py:101-107.  torch.cumsum on the CPU (what the oracle and the golden vectors were produced
     // with) accumulates float32 inputs in double and rounds every prefix back to float; it is mirrored here
@@ -248,7 +261,7 @@ __device__ __forceinline__ Placed place_sample(const RayBoxes &rb, int M, const 
     }
     const float total = fminf(run, sample_depth);
     // :118-135 deterministic stratified points and their midpoints
-    const float s0 = lin[sidx] * total, s1 = lin[sidx + 1] * total;
+    const float s0 = strat_pos(lin, u, n_points, sidx) * total, s1 = strat_pos(lin, u, n_points, sidx + 1) * total;
     const float mid = (s1 + s0) / 2.f;
     Placed o;
     o.dist = s1 - s0;
@@ -269,6 +282,8 @@ __device__ __forceinline__ Placed place_sample(const RayBoxes &rb, int M, const 
         }
     }
     float depth = head + mid;  // :149
+    o.raw_depth = depth;
+    o.raw_idx = idx;
     if (depth != depth || __builtin_isinf(depth)) depth = 0.f;  // scenedreamer.py:350-352
     o.depth = depth;
     o.idx = idx < M ? idx : M - 1;
@@ -323,7 +338,8 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
     for (int ch = 0; ch < p.nch; ch++) {
         const int sidx = ch * SAMP_PER_STEP + (j & 3);
         const bool valid = ray_ok && sidx < p.ns;
-        const Placed pl = place_sample(rb, p.M, p.lin, valid ? sidx : 0, p.sample_depth);
+        const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)rr * (p.ns + 1) : nullptr, p.ns + 1, valid ? sidx : 0,
+                                       p.sample_depth);
         const float wx = mul_add_exact(d0, pl.depth, p.ori[0]);  // scenedreamer.py:354
         const float wy = mul_add_exact(d1, pl.depth, p.ori[1]);
         const float wz = mul_add_exact(d2, pl.depth, p.ori[2]);
@@ -394,6 +410,46 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
             if (k == p.M - 1) last = rb.id[k];
         const bool nosky = (last != 0) || gnd;           // :335, :382
         p.rayflag[ray] = (uint8_t)((sky_only ? 1 : 0) | (nosky ? 2 : 0));
+    }
+}
+
+// =====================================================================================================
+// mc_utils.sample_depth_batched as an op of its own (the un-fused path and training): one thread per ray
+// =====================================================================================================
+struct SampleParams {
+    const float *depth2;   // [2, R, M]
+    const float *lin;      // [n_points]
+    const float *u;        // [R, n_points] or nullptr
+    float *rand_depth;     // [R, n_points - 1]
+    float *new_dists;      // [R, n_points - 1]
+    int64_t *idx;          // [R, n_points - 1]
+    int32_t R, M, n_points;
+    float sample_depth;
+};
+
+__global__ __launch_bounds__(256) void sample_depth_kernel(const SampleParams p) {
+    const int ray = blockIdx.x * 256 + threadIdx.x;
+    if (ray >= p.R) return;
+    RayBoxes rb;
+#pragma unroll
+    for (int k = 0; k < MAXM; k++) {
+        if (k < p.M) {
+            rb.t[k] = p.depth2[(size_t)ray * p.M + k];
+            rb.t2[k] = p.depth2[((size_t)p.R + ray) * p.M + k];
+        } else {
+            rb.t[k] = rb.t2[k] = __builtin_nanf("");
+        }
+        rb.id[k] = 0;
+    }
+    const float *u = p.u ? p.u + (size_t)ray * p.n_points : nullptr;
+    const int ns = p.n_points - 1;
+    for (int i = 0; i < ns; i++) {
+        Placed pl = place_sample(rb, p.M, p.lin, u, p.n_points, i, p.sample_depth);
+        // the op returns the RAW values: NaN depths of rays that hit nothing are zeroed by the caller (scenedreamer.py:350-352)
+        // and the box index is the count itself, mc_utils.py:139 (place_sample clamps it for the label lookup)
+        p.new_dists[(size_t)ray * ns + i] = pl.dist;
+        p.rand_depth[(size_t)ray * ns + i] = pl.raw_depth;
+        p.idx[(size_t)ray * ns + i] = pl.raw_idx;
     }
 }
 
@@ -1484,8 +1540,8 @@ size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples) {
 
 int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
-                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, int32_t n_rays,
-                     int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
+                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
+                     int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
                      float *dist, uint8_t *label, uint8_t *rayflag, sdn_stream_t stream) {
     SDN_REQUIRE(voxel_id && depth2 && raydirs && lut1024 && table3 && scales_dev && genc_host && cam_ori_host &&
                     voxel_dims_host && lin_dev && feat && dist && label && rayflag,
@@ -1509,9 +1565,22 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
     for (int i = 0; i < 3; i++) { p.ori[i] = cam_ori_host[i]; p.delim[i] = voxel_dims_host[i]; }
     p.sample_depth = sample_depth; p.dists_scale = dists_scale;
     p.lin = lin_dev;
+    p.u = u_dev;
     p.scales = scales_dev;
     hipLaunchKernelGGL(encode_kernel, dim3(sdn::div_up(p.n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_encode");
+}
+
+int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_dev, int32_t n_rays, int32_t max_blocks,
+                     int32_t n_points, float sample_depth, float *rand_depth, float *new_dists, int64_t *idx, sdn_stream_t stream) {
+    SDN_REQUIRE(depth2 && lin_dev && rand_depth && new_dists && idx, "sdn_sample_depth: null pointer");
+    SDN_REQUIRE(n_rays > 0 && n_points >= 2, "sdn_sample_depth: need at least one ray and two stratified points");
+    if (max_blocks < 1 || max_blocks > MAXM) return sdn::fail(SDN_ERR_UNSUPPORTED, "sdn_sample_depth: max_blocks must be 1..8");
+    SampleParams p;
+    p.depth2 = depth2; p.lin = lin_dev; p.u = u_dev; p.rand_depth = rand_depth; p.new_dists = new_dists; p.idx = idx;
+    p.R = n_rays; p.M = max_blocks; p.n_points = n_points; p.sample_depth = sample_depth;
+    hipLaunchKernelGGL(sample_depth_kernel, dim3(sdn::div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_sample_depth");
 }
 
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,

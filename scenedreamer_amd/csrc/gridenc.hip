@@ -407,8 +407,15 @@ __global__ __launch_bounds__(256) void grid_input_bwd_kernel(const T *__restrict
         for (uint32_t l = 0; l < L; l++) {
 #pragma unroll
             for (uint32_t c = 0; c < C; c++) {
-                const __half prod = __float2half(__half2float(grad[((uint64_t)l * B + b) * C + c]) * __half2float(dd[(l * D + d) * C + c]));
-                r = __float2half(__half2float(r) + __half2float(prod));
+                // at::Half arithmetic is "convert to float, operate, round back" (c10/util/Half-inl.h): the SUM of two
+                // halfs is rounded to f32 first, then to half.  The empty asm keeps hipcc from contracting the chain into
+                // native half instructions (v_add_f16 / v_fma_mix round once and differ by an ulp now and then).
+                float prod = __half2float(grad[((uint64_t)l * B + b) * C + c]) * __half2float(dd[(l * D + d) * C + c]);
+                float prod_h = __half2float(__float2half(prod));
+                asm volatile("" : "+v"(prod_h));
+                float sum = __half2float(r) + prod_h;
+                asm volatile("" : "+v"(sum));
+                r = __float2half(sum);
             }
         }
         grad_inputs[t] = r;

@@ -90,16 +90,25 @@ def _buffers(R, n_rays, ns, slot=0):
     return cache[key]
 
 
-def encode(R, vid, d2, rd, cam_ori, ns, buf=None):
+def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None):
+    """u: None = deterministic sampling (inference); f32 [n_rays, ns + 1] uniform randoms (the caller's
+    torch.rand(..., ns + 1) draw, mc_utils.py:121) = the training-time stratified sampling."""
     sc = R._fused_scene or prepare_scene(R)
     n_rays = vid.shape[0]
     buf = buf or _buffers(R, n_rays, ns)
+    lin = buf["lin"]
+    if u is not None:
+        assert u.is_cuda and u.dtype == torch.float32 and tuple(u.shape) == (n_rays, ns + 1) and u.is_contiguous()
+        lin = buf.get("lin_strat")
+        if lin is None:
+            lin = buf["lin_strat"] = torch.linspace(0, 1, ns + 2)[:-1].contiguous().to(R.dev)   # mc_utils.py:124
     ori = np.asarray(cam_ori.detach().cpu().numpy() if isinstance(cam_ori, torch.Tensor) else cam_ori, np.float32)
     with torch.cuda.device(R.dev):
         rc = _lib().sdn_field_encode(vid.data_ptr(), d2.data_ptr(), rd.data_ptr(), sc["lut"].data_ptr(),
                                      sc["table3"].data_ptr(), sc["T"], sc["scales"].data_ptr(),
                                      sc["genc"].ctypes.data, ori.ctypes.data, sc["dims"].ctypes.data,
-                                     buf["lin"].data_ptr(), n_rays, R.M, ns, R.sample_depth, R.dists_scale,
+                                     lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M, ns,
+                                     R.sample_depth, R.dists_scale,
                                      buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
                                      buf["rayflag"].data_ptr(), _stream(R.dev))
     capi.check(rc, "sdn_field_encode")
@@ -148,7 +157,7 @@ def single_chunk(n_rays, ns):
     return n_rays * (_lib().sdn_field_feat_bytes(32, ns) // 32) <= FEATURE_BUFFER_BYTES
 
 
-def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None):
+def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None):
     """net_out [R,64] for intersections vid [R,M] / d2 [2,R,M] / raydirs rd [R,3].
     Rays are independent, so very large frames (4K x 40 samples = 174 GB of features) go through in ray chunks that
     reuse one feature buffer; the headline frame (6.9 GB) is a single chunk."""
@@ -161,7 +170,7 @@ def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None):
     for r0 in range(0, n_rays, chunk):
         r1 = min(n_rays, r0 + chunk)
         v, d, r_, s_ = vid[r0:r1].contiguous(), d2[:, r0:r1].contiguous(), rd[r0:r1].contiguous(), sky_c[r0:r1].contiguous()
-        buf = encode(R, v, d, r_, cam_ori, ns)
+        buf = encode(R, v, d, r_, cam_ori, ns, u=u[r0:r1].contiguous() if u is not None else None)
         _launch_mlp(R, buf, st, s_, net_out[r0:r1], r1 - r0, ns, passes[r0 // 32:] if passes is not None else None)
     return net_out
 

@@ -95,6 +95,39 @@ def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f
     return [voxel_id, depth2, raydirs]
 
 
+def sample_depth_batched(depth2, nsamples, deterministic=False, use_box_boundaries=True, sample_depth=4, rand=None):
+    """mc_utils.sample_depth_batched (imaginaire/model_utils/gancraft/mc_utils.py:82-151), same signature and return
+    values: depth2 [N,2,H,W,M,1] -> (rand_depth [N,H,W,nsamples-1,1], new_dists likewise, idx int64 likewise).
+    `rand` (not in the reference signature): the uniform randoms of the stochastic branch, [N,H,W,nsamples,1]; by default
+    drawn with torch.rand exactly as the reference does (:121), so a seeded call reproduces the reference's samples.
+    use_box_boundaries=True (unused by SceneDreamer's configs, scenedreamer_train.yaml:121) is not implemented."""
+    _require(isinstance(depth2, torch.Tensor) and depth2.is_cuda and depth2.dtype == torch.float32, "depth2 must be a CUDA float32 tensor")
+    _require(depth2.dim() == 6 and depth2.shape[1] == 2 and depth2.shape[-1] == 1, "depth2 must be [N,2,H,W,M,1]")
+    if use_box_boundaries:
+        raise NotImplementedError("sample_depth_batched(use_box_boundaries=True)")
+    N, _, H, W, M, _ = depth2.shape
+    dev = depth2.device
+    R = N * H * W
+    d2 = depth2.permute(1, 0, 2, 3, 4, 5).reshape(2, R, M).contiguous()
+    if deterministic:
+        lin = torch.linspace(0, 1, nsamples + 2)[1:-1].contiguous().to(dev)
+        u = None
+    else:
+        lin = torch.linspace(0, 1, nsamples + 1)[:-1].contiguous().to(dev)
+        if rand is None:
+            rand = torch.rand([N, H, W, nsamples, 1], dtype=depth2.dtype, device=dev)
+        u = rand.reshape(R, nsamples).contiguous()
+    with torch.cuda.device(dev):
+        depth = torch.empty((R, nsamples - 1), dtype=torch.float32, device=dev)
+        dists = torch.empty_like(depth)
+        idx = torch.empty((R, nsamples - 1), dtype=torch.int64, device=dev)
+        capi.check(capi.lib().sdn_sample_depth(d2.data_ptr(), lin.data_ptr(), u.data_ptr() if u is not None else None, R, M,
+                                               nsamples, float(sample_depth), depth.data_ptr(), dists.data_ptr(),
+                                               idx.data_ptr(), _stream(depth2)), "sdn_sample_depth")
+    shape = (N, H, W, nsamples - 1, 1)
+    return depth.view(shape), dists.view(shape), idx.view(shape)
+
+
 def _pe_sizes(t, dim):
     if dim < 0:
         dim = t.dim() + dim

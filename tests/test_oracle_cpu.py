@@ -24,6 +24,22 @@ def test_field_ref_reproduces_reference_golden(oracle, weights_full, scene256, l
         np.testing.assert_allclose(img.numpy(), g["image"], rtol=0, atol=1e-6)
 
 
+def test_sample_depth_oracle_reproduces_reference_golden():
+    """oracle/field_ref.sample_depth_batched (deterministic and the training-time stochastic branch, fed with the stored
+    torch.rand draw) == the unmodified mc_utils.sample_depth_batched (oracle/make_golden_sampling.py), bit for bit."""
+    from oracle import field_ref as FR
+    g = golden("stochastic_sampling.npz")
+    d2 = torch.from_numpy(g["depth2"])
+    for ns in (13, 25):
+        rd, nd, idx = FR.sample_depth_batched(d2.clone(), ns, 3.0, rand=g[f"u{ns}"])
+        np.testing.assert_array_equal(idx.numpy().astype(np.int8), g[f"idx{ns}"])
+        np.testing.assert_array_equal(bits(rd.numpy()), bits(g[f"depth{ns}"]))
+        np.testing.assert_array_equal(bits(nd.numpy()), bits(g[f"dists{ns}"]))
+        rd, nd, idx = FR.sample_depth_batched(d2.clone(), ns, 3.0)
+        np.testing.assert_array_equal(idx.numpy().astype(np.int8), g[f"det_idx{ns}"])
+        np.testing.assert_array_equal(bits(rd.numpy()), bits(g[f"det_depth{ns}"]))
+
+
 def test_style_and_scene_codes_reproduce_reference_golden(weights_full, scene256):
     from oracle import field_ref as FR
     from scenedreamer_amd import synth
