@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--bench-mode", default="frames", choices=["frames", "tile-parallel"],
                     help="frames: every rank renders whole frames (frame f -> rank f %% N); tile-parallel: every step is ONE "
                          "frame whose row bands are rendered by the N ranks (BASELINE config 5)")
+    ap.add_argument("--volume", default="compact", choices=["compact", "int32"],
+                    help="scene volume the rays walk: uint8 palette indices + int32 palette (scene.py, 4x smaller, what the "
+                         "ranks receive; voxel ids come out identical) or the reference's int32 block ids")
     ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
                     help="BASELINE.json configs[i-1]: sets resolution / samples / cam_maxstep / bench mode / steps")
     args = ap.parse_args()
@@ -175,9 +178,13 @@ def main():
     bstats = {}
     if world > 1:
         t_b = time.time()
-        scene, weights, style = sdist.broadcast_state(scene, weights, style, dev, src=0, stats=bstats)
+        scene, weights, style = sdist.broadcast_state(scene, weights, style, dev, src=0, stats=bstats,
+                                                      compact=args.volume == "compact")
         torch.cuda.synchronize()
         bstats["broadcast_s"] = time.time() - t_b
+    elif args.volume == "compact":
+        from scenedreamer_amd import scene as scene_mod
+        scene = scene_mod.to_compact(scene)
     R = Renderer(weights, scene, dev)
     R.set_style(style)
     maxstep = args.cam_maxstep
@@ -283,6 +290,7 @@ def main():
                        "baseline_config": args.config or (2 if (hw, args.samples, args.scene_size) == ((540, 960), 24, 2048) else None),
                        "path": mode, "apron": "reference" if tile_parallel else args.apron,
                        "ray_casting_overlap": not (args.no_overlap or mode != "fused"),
+                       "scene_volume": ("uint8 palette indices" if getattr(scene, "voxel_u8", None) is not None else "int32 block ids"),
                        "padded_rays": (hw[0] + 30) * (hw[1] + 30),
                        "field_rays": (hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30),
                        "samples_per_frame": ((hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30)) * args.samples,

@@ -84,6 +84,18 @@ def compact(voxel_t):
     return out, torch.from_numpy(palette).to(dev)
 
 
+def to_compact(scene):
+    """A CompactScene holding the same world as `scene` (any object with the reference's scene-handle attributes and an
+    int32 `voxel_t` on the GPU); the int32 volume is not kept."""
+    if getattr(scene, "voxel_u8", None) is not None:
+        return scene
+    sc = CompactScene()
+    sc.voxel_u8, sc.palette = compact(scene.voxel_t)
+    sc.heightmap, sc.trans_mat, sc.sample_size = scene.heightmap, scene.trans_mat, scene.sample_size
+    sc.current_height_map, sc.current_semantic_map = scene.current_height_map, scene.current_semantic_map
+    return sc
+
+
 def normalise_height_map(height_map):
     """pcg_gen.py:94-95."""
     hm = np.array(height_map, dtype=np.float64 if np.asarray(height_map).dtype == np.float64 else np.float32, copy=True)
