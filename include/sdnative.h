@@ -161,6 +161,8 @@ size_t sdn_field_consts_floats(void);
 int sdn_field_const_offset(int which);
 size_t sdn_field_feat_bytes(int32_t n_rays, int32_t num_samples);
 size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples);
+/* int32 elements of the optional work list encode writes for mlp: [hit groups][other groups][one entry per 32-ray group] */
+size_t sdn_field_worklist_elems(int32_t n_rays);
 
 /* embeddings dev f32 [sO,8]; offsets_host int32[L+1]; genc_host f32[2] = world_encoder output;
  * table3 dev f32 [16, T, 8] (T = rows per level) */
@@ -175,12 +177,20 @@ int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const 
  * rayflag u8 [R].  Sample placement = mc_utils.sample_depth_batched(nsamples = num_samples + 1, use_box_boundaries =
  * False): deterministic (inference) with u_dev = NULL and lin_dev f32 [num_samples+1] = linspace(0,1,num_samples+3)[1:-1];
  * stochastic / stratified (training, mc_utils.py:121-125) with u_dev f32 [R, num_samples+1] = the caller's torch.rand draw
- * and lin_dev = linspace(0,1,num_samples+2)[:-1]. */
+ * and lin_dev = linspace(0,1,num_samples+2)[:-1].
+ * window_host: NULL (the n_rays rays are rays 0..n_rays-1 of voxel_id / depth2 / raydirs), or host int32[5]
+ *   {n_src, pitch, first, cols, ray0}: the arrays hold n_src rays (the whole padded frame the ray marcher wrote, as the
+ *   reference's per-frame voxlib call does, scenedreamer.py:576-590) and local ray r is ray w = ray0 + r of a window of
+ *   `cols` columns whose ray (y, x) is source ray first + y * pitch + x (cols = 0: source ray = ray0 + r).  Outputs
+ *   (feat, dist, label, rayflag) and u_dev are indexed by the LOCAL ray.
+ * worklist: NULL, or dev int32 [sdn_field_worklist_elems(n_rays)], filled for sdn_field_mlp: the 32-ray groups with a
+ *   ray that hits something (count in [0], indices from [2] on) and those without (count in [1], indices from the end). */
 int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
                      int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
-                     float *dist, uint8_t *label, uint8_t *rayflag, sdn_stream_t stream);
+                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, int32_t *worklist,
+                     sdn_stream_t stream);
 /* mc_utils.sample_depth_batched (imaginaire/model_utils/gancraft/mc_utils.py:82-151, use_box_boundaries = False) as an op:
  * depth2 dev f32 [2,R,M] -> rand_depth, new_dists dev f32 [R, n_points-1], idx dev i64 [R, n_points-1] (raw values: NaN
  * depths of rays without a hit are left for the caller to zero, scenedreamer.py:350-352).  lin_dev / u_dev as above with
@@ -191,10 +201,16 @@ int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_d
  * colour_terms: f16 split terms of the colour layers fc_5 / fc_6: 3 (like every other layer) or 2 (without Whi.Xlo).
  * term_eps: early ray termination -- a 32-ray group stops sampling once the transmittance of all its rays is below
  *   term_eps (changes net_out by at most 2 * term_eps); 0 = off (the reference evaluates every sample).
- * passes: optional dev u8 [ceil(ceil(R / 8) / 4)], number of 4-sample passes every 32-ray group went through. */
+ * passes: optional dev u8 [ceil(ceil(R / 8) / 4)], number of 4-sample passes every 32-ray group went through.
+ * window_host: as for sdn_field_encode; it applies to sky_c (indexed by the SOURCE ray: the sky MLP covers the whole
+ *   padded frame), net_out is indexed by the local ray.
+ * sky_avg: NULL (the value at const offset 5 is used) or dev f32 [64], the frame mean sdn_sky_mlp finished.
+ * worklist: NULL (every group is visited, groups whose 32 rays hit nothing are skipped) or the list the matching
+ *   sdn_field_encode call wrote (hit groups are dealt round-robin to the persistent workgroups: equal shares). */
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
-                  int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, sdn_stream_t stream);
+                  int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
+                  const float *sky_avg, const int32_t *worklist, sdn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Render CNN: the convolutions of RenderCNN (imaginaire/generators/gancraft_base.py:175-225, forward :202-225) on MFMA
@@ -230,13 +246,16 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms,
  * consts (sdn_sky_consts_floats floats): [fc1.bias + fc_z_a(z) : 256][fc2..fc5 bias : 4x256][fc_out_c.bias : 64];
  * w1 dev [256,33]; wh4_host host array of 4 dev pointers [256,256]; wc dev [64,256];
  * sky_partial dev f32 [sdn_sky_partial_rows(n_rays, n_workgroups), 64]: every wave's sum of its rays' sky_c (all rows are
- * written; the caller adds them up -- no float atomics, the mean is reproducible bit for bit). */
+ * written -- no float atomics, the mean is reproducible bit for bit).
+ * sky_avg + counter (both or neither): dev f32 [64] and a dev uint32 that is ZERO before the first launch; the last
+ * workgroup to finish adds the partial rows in row order (double accumulation) and writes the frame mean sum / n_rays,
+ * then resets the counter.  Without them the caller adds the rows up. */
 int32_t sdn_sky_partial_rows(int32_t n_rays, int32_t n_workgroups);
 size_t sdn_sky_packed_weight_bytes(void);
 size_t sdn_sky_consts_floats(void);
 int sdn_sky_pack_weights(const float *w1, const float *const *wh4_host, const float *wc, void *packed, sdn_stream_t stream);
 int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_partial, int32_t n_rays,
-                int32_t n_workgroups, sdn_stream_t stream);
+                int32_t n_workgroups, float *sky_avg, uint32_t *counter, sdn_stream_t stream);
 
 /* test hook: C[32,32] = A[32,16] * B[16,32] through the MFMA operand layouts field.hip relies on */
 int sdn_debug_mfma_probe(const float *A, const float *B, float *C, sdn_stream_t stream);

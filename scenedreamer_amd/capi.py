@@ -52,15 +52,16 @@ _SIGNATURES = {
     "sdn_field_collapse_table": (c_i, [c_p, c_p, c_u, c_f, c_u, c_p, c_p, c_p]),
     "sdn_field_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_field_encode": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
-                               ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+                               ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "sdn_field_worklist_elems": (ctypes.c_size_t, [ctypes.c_int32]),
     "sdn_sample_depth": (c_i, [c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p]),
     "sdn_field_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
-                            ctypes.c_float, c_p, ctypes.c_int32, c_p]),
+                            ctypes.c_float, c_p, ctypes.c_int32, c_p, c_p, c_p, c_p]),
     "sdn_sky_packed_weight_bytes": (ctypes.c_size_t, []),
     "sdn_sky_consts_floats": (ctypes.c_size_t, []),
     "sdn_sky_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_sky_partial_rows": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
-    "sdn_sky_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, c_p]),
+    "sdn_sky_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p, c_p]),
     "sdn_conv_plane_dims": (None, [c_i, c_i, c_p, c_p]),
     "sdn_conv_packed_weight_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "sdn_conv_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),

@@ -76,6 +76,26 @@ constexpr int C_BSIGMA = C_BC + OUTC;                // [1]
 constexpr int C_SKY_AVG = C_BSIGMA + 4;              // [64]
 constexpr int C_TOTAL = C_SKY_AVG + OUTC;
 
+// The rays of a launch are a WINDOW of the ray arrays the ray marcher wrote for the whole padded frame (the field is
+// evaluated on the 4-px apron the image can depend on, a band of rows, or a chunk of either): local ray r is ray
+// w = ray0 + r of a window of `cols` columns whose ray (y, x) is source ray first + y * pitch + x.  No window: cols = 0,
+// source ray = ray0 + r.  Reading through the window replaces four strided-slice copies per frame on the host side.
+struct RayWindow {
+    int32_t n_src;             // rays in the source arrays (stride of depth2's two planes)
+    int32_t pitch, first, cols, ray0;
+    __device__ __forceinline__ int src(int r) const {
+        const int w = ray0 + r;
+        return cols > 0 ? first + (w / cols) * pitch + (w % cols) : w;
+    }
+};
+
+// Work list of the field MLP, filled by encode_kernel (one workgroup = 4 ray tiles = one 32-ray group of mlp_kernel):
+// wl[0] = number of groups with at least one ray that hits something, their indices in wl[2 .. 2 + wl[0]) (any order);
+// wl[1] = number of groups that hit nothing, their indices from the END of the array backwards.  The persistent MLP
+// workgroups take the hit groups round-robin, so every workgroup gets the same number of them to within one
+// (a static g % 256 assignment of ALL groups left workgroups whose share was mostly sky idle at the end: 2-4 %).
+constexpr int WL_HEAD = 2;
+
 struct EncParams {
     const int32_t *voxel_id;   // [R, M]
     const float *depth2;       // [2, R, M]
@@ -94,6 +114,8 @@ struct EncParams {
     const float *lin;          // dev [ns+1]  deterministic: linspace(0,1,ns+3)[1:-1]; stochastic: linspace(0,1,ns+2)[:-1]
     const float *u;            // dev [R][ns+1] uniform randoms of the training-time stratified sampling, or nullptr
     const float *scales;       // dev [16]    per-level scale, exp2f(l*S)*H-1 evaluated on the host
+    RayWindow win;             // where ray r of this launch lives in voxel_id / depth2 / raydirs
+    int32_t *worklist;         // optional [2 + n_groups]: see Worklist below
 };
 
 struct MlpParams {
@@ -108,6 +130,9 @@ struct MlpParams {
     int32_t R, ns, nch, n_tiles;
     float term_depth;          // early ray termination: optical depth -ln(eps) beyond which a ray is opaque; <= 0: off
     uint8_t *passes;           // optional [ceil(n_tiles / 4)]: passes every 32-ray group went through (tests / bench)
+    RayWindow win;             // sky_c is indexed with the SOURCE ray (it covers the whole padded frame)
+    const float *sky_avg;      // optional dev [64]: frame mean of sky_c (else the value inside `consts`)
+    const int32_t *worklist;   // optional: groups to evaluate, written by encode_kernel
 };
 
 // =====================================================================================================
@@ -307,20 +332,23 @@ __device__ __forceinline__ float normalise_coord(float wc, float delim) {
 }
 
 __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
-    const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= p.n_tiles) return;
+    __shared__ int s_hit[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wave;
+    const bool tile_ok = tile < p.n_tiles;
     const int h = lane >> 5, j = lane & 31;
     const int ray = tile * RAYS_PER_TILE + (j >> 2);
-    const bool ray_ok = ray < p.R;
-    const int rr = ray_ok ? ray : p.R - 1;
+    const bool ray_ok = tile_ok && ray < p.R;
+    const int rl = ray_ok ? ray : p.R - 1;      // local ray (index into u / rayflag)
+    const int rr = p.win.src(rl);               // the same ray in the source arrays
+    const size_t RS = (size_t)p.win.n_src;
 
     RayBoxes rb;
 #pragma unroll
     for (int k = 0; k < MAXM; k++) {
         if (k < p.M) {
             rb.t[k] = p.depth2[(size_t)rr * p.M + k];
-            rb.t2[k] = p.depth2[((size_t)p.R + rr) * p.M + k];
+            rb.t2[k] = p.depth2[(RS + rr) * p.M + k];
             rb.id[k] = p.voxel_id[(size_t)rr * p.M + k];
         } else {
             rb.t[k] = rb.t2[k] = __builtin_nanf("");
@@ -334,11 +362,21 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
     // (the MLP kernel reads whatever is there and discards the result by selection, not multiplication).
     const bool use_feat = ray_ok && rb.id[0] != 0;
     const bool tile_dead = !__any(use_feat);
+    if (p.worklist) {   // this workgroup's 32-ray group goes on the MLP's work list (hit groups from the front, others from the back)
+        if (lane == 0) s_hit[wave] = tile_dead ? 0 : 1;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n_groups = (p.n_tiles + 3) >> 2;
+            if (s_hit[0] | s_hit[1] | s_hit[2] | s_hit[3]) p.worklist[WL_HEAD + atomicAdd(&p.worklist[0], 1)] = blockIdx.x;
+            else p.worklist[WL_HEAD + n_groups - 1 - atomicAdd(&p.worklist[1], 1)] = blockIdx.x;
+        }
+    }
+    if (!tile_ok) return;
 
     for (int ch = 0; ch < p.nch; ch++) {
         const int sidx = ch * SAMP_PER_STEP + (j & 3);
         const bool valid = ray_ok && sidx < p.ns;
-        const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)rr * (p.ns + 1) : nullptr, p.ns + 1, valid ? sidx : 0,
+        const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)rl * (p.ns + 1) : nullptr, p.ns + 1, valid ? sidx : 0,
                                        p.sample_depth);
         const float wx = mul_add_exact(d0, pl.depth, p.ori[0]);  // scenedreamer.py:354
         const float wy = mul_add_exact(d1, pl.depth, p.ori[1]);
@@ -997,6 +1035,14 @@ __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], h
     out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, bias_pend, h, part);
 }
 
+// wave-uniform 4-byte load through the scalar cache (an ordinary load here would make hipcc's wait insertion drain the
+// weight ring's DMA queue -- vmcnt(0) -- wherever the value is used)
+__device__ __forceinline__ int sload(const int32_t *ptr) {
+    int v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
+    return v;
+}
+
 // CT = number of split terms of the colour layers fc_5 / fc_6 (3, or 2 = without the Whi.Xlo products)
 template <int DBG, int CT>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
@@ -1006,7 +1052,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     const int q = j & 3;
 
     float *cst = reinterpret_cast<float *>(lds + LDS_CONST);
-    for (int i = threadIdx.x; i < C_TOTAL; i += 256) cst[i] = p.consts[i];
+    // the frame mean of the sky features arrives straight from sky_kernel (no host-side copy into the constant block).
+    // ONE writer per LDS word: two waves writing the same word without a barrier in between land in either order.
+    static_assert(C_SKY_AVG + OUTC == C_TOTAL, "sky_avg is the tail of the constant block");
+    for (int i = threadIdx.x; i < C_TOTAL; i += 256)
+        cst[i] = (p.sky_avg && i >= C_SKY_AVG) ? p.sky_avg[i - C_SKY_AVG] : p.consts[i];
     __syncthreads();
 
     Ring r;
@@ -1036,7 +1086,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     unsigned n_pass = 0;
     if constexpr (DBG & 128) t_kernel0 = __builtin_readcyclecounter();
     const int n_groups = (p.n_tiles + 3) >> 2;
-    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // With a work list (written by encode_kernel) the loop runs over the groups that hit something, then over the ones
+    // that do not (sky blend only); without one over all groups, a group being skipped when none of its rays hits.
+    const int n_hit = p.worklist ? sload(p.worklist) : n_groups;
+    const int n_items = p.worklist ? n_hit + sload(p.worklist + 1) : n_groups;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        // item -> group: hit groups from the front of the list, the others from its end
+        const int grp = p.worklist ? sload(p.worklist + WL_HEAD + (it < n_hit ? it : n_groups - 1 - (it - n_hit))) : it;
         const int tile = grp * 4 + wave;
         const bool tile_ok = tile < p.n_tiles;
         const int tile_s = grp * 4 + r.wave;              // the same as scalars (r.wave went through readfirstlane)
@@ -1044,17 +1100,22 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         const int ray = tile * RAYS_PER_TILE + (j >> 2);
         const bool ray_ok = tile_ok && ray < p.R;
         const uint8_t flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
-        const bool any_hit = __any(!(flag & 1));
-        // workgroup-uniform decision: skip the group when none of its 32 rays hits anything
         volatile int *flags = reinterpret_cast<volatile int *>(lds + LDS_FLAGS);
-        if (lane == 0) flags[wave] = any_hit ? 1 : 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // readfirstlane makes the decision provably uniform: otherwise every loop-carried ring counter / pointer is
-        // classified divergent, lives in VGPRs (spills!) and the DMA cannot use scalar addressing
-        const bool grp_hit = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // the next group rewrites the flags only after everyone has read them
+        bool grp_hit;
+        if (p.worklist) {
+            grp_hit = it < n_hit;
+        } else {
+            const bool any_hit = __any(!(flag & 1));
+            // workgroup-uniform decision: skip the group when none of its 32 rays hits anything
+            if (lane == 0) flags[wave] = any_hit ? 1 : 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // readfirstlane makes the decision provably uniform: otherwise every loop-carried ring counter / pointer is
+            // classified divergent, lives in VGPRs (spills!) and the DMA cannot use scalar addressing
+            grp_hit = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // the next group rewrites the flags only after everyone has read them
+        }
 
         float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float carry = 0.f, tsum = 0.f;
@@ -1148,7 +1209,14 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 long tn = tc_s + 1;
                 bool has_next = tile_ok_s;
                 if (ch + 1 == p.nch) {
-                    const int tile2 = (grp + (int)gridDim.x) * 4 + r.wave;
+                    // first step of this wave's tile in the workgroup's next group (work list: its next HIT group)
+                    const int it2 = it + (int)gridDim.x;
+                    int tile2 = p.n_tiles;
+                    if (p.worklist) {
+                        if (it2 < n_hit) tile2 = sload(p.worklist + WL_HEAD + it2) * 4 + r.wave;
+                    } else {
+                        tile2 = it2 * 4 + r.wave;
+                    }
                     has_next = tile2 < p.n_tiles;
                     tn = (long)tile2 * p.nch;
                 }
@@ -1230,7 +1298,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
 #pragma unroll
             for (int ib = 0; ib < 2; ib++) {
                 const int f0 = 32 * ib + 8 * q + 4 * h;   // this lane owns features f0 .. f0+3 of its ray
-                const float4 sc = *reinterpret_cast<const float4 *>(p.sky_c + (size_t)ray * OUTC + f0);
+                const float4 sc = *reinterpret_cast<const float4 *>(p.sky_c + (size_t)p.win.src(ray) * OUTC + f0);
                 const float4 sa = *reinterpret_cast<const float4 *>(cst + C_SKY_AVG + f0);
                 const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, sav[4] = {sa.x, sa.y, sa.z, sa.w};
                 float o[4];
@@ -1279,6 +1347,8 @@ struct SkyParams {
     float *sky_c;           // [R,64]
     float *sky_partial;     // [4 * gridDim.x][64]: every wave's sum of sky_c over its rays (summed by the caller: no float
                             // atomics, so the frame mean is reproducible bit for bit)
+    float *sky_avg;         // optional [64]: frame mean of sky_c, finished by the last workgroup to arrive
+    unsigned int *counter;  // with sky_avg: arrival counter, zero before the first launch (the kernel leaves it at zero)
     int32_t R, n_tiles;
 };
 
@@ -1424,6 +1494,27 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // ---- frame mean (scenedreamer.py:592-598): the last workgroup to arrive adds the partial rows of ALL workgroups in
+    //      row order (fixed order, double accumulation: reproducible bit for bit, unlike float atomics) ----------------
+    if (p.sky_avg == nullptr) return;
+    int *ticket = reinterpret_cast<int *>(lds + LDS_FLAGS);
+    double *red = reinterpret_cast<double *>(lds + LDS_RING);      // the weight ring is idle now
+    __threadfence();                                               // this workgroup's rows are visible device-wide ...
+    if (threadIdx.x == 0) *ticket = (int)atomicAdd(p.counter, 1u); // ... before its arrival is counted
+    __syncthreads();
+    if (*ticket != (int)gridDim.x - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int rows = 4 * (int)gridDim.x, f = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int r0 = part * (rows / 4), r1 = r0 + rows / 4;          // four consecutive quarters of the rows
+    double acc_d = 0.0;
+    for (int rw = r0; rw < r1; rw++) acc_d += (double)__builtin_nontemporal_load(p.sky_partial + (size_t)rw * OUTC + f);
+    red[threadIdx.x] = acc_d;
+    __syncthreads();
+    if (threadIdx.x < OUTC) {
+        const double tot = ((red[f] + red[64 + f]) + red[128 + f]) + red[192 + f];
+        p.sky_avg[f] = (float)(tot / (double)p.R);
+    }
+    if (threadIdx.x == 0) *p.counter = 0u;                         // ready for the next launch
 }
 
 // =====================================================================================================
@@ -1538,11 +1629,31 @@ size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples) {
     return tiles * nch * 32;
 }
 
+// window_host: NULL, or {n_src, pitch, first, cols, ray0} (see RayWindow)
+static int set_window(RayWindow &w, const int32_t *window_host, int32_t n_rays, const char *who) {
+    if (window_host == nullptr) {
+        w.n_src = n_rays; w.pitch = 0; w.first = 0; w.cols = 0; w.ray0 = 0;
+        return 0;
+    }
+    w.n_src = window_host[0]; w.pitch = window_host[1]; w.first = window_host[2]; w.cols = window_host[3]; w.ray0 = window_host[4];
+    if (w.n_src <= 0 || w.cols < 0 || w.ray0 < 0 || w.first < 0 || w.pitch < 0)
+        return sdn::fail(SDN_ERR_INVALID, "%s: bad ray window", who);
+    const long last = (long)w.ray0 + n_rays - 1;
+    const long src_last = w.cols > 0 ? (long)w.first + (last / w.cols) * w.pitch + (w.cols - 1) : last;
+    if (src_last >= w.n_src) return sdn::fail(SDN_ERR_INVALID, "%s: ray window reaches outside the %d source rays", who, w.n_src);
+    return 0;
+}
+
+size_t sdn_field_worklist_elems(int32_t n_rays) {
+    return (size_t)WL_HEAD + (size_t)sdn::div_up(sdn::div_up(n_rays, RAYS_PER_TILE), 4);
+}
+
 int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
                      int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
-                     float *dist, uint8_t *label, uint8_t *rayflag, sdn_stream_t stream) {
+                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, int32_t *worklist,
+                     sdn_stream_t stream) {
     SDN_REQUIRE(voxel_id && depth2 && raydirs && lut1024 && table3 && scales_dev && genc_host && cam_ori_host &&
                     voxel_dims_host && lin_dev && feat && dist && label && rayflag,
                 "sdn_field_encode: null pointer");
@@ -1567,6 +1678,12 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
     p.lin = lin_dev;
     p.u = u_dev;
     p.scales = scales_dev;
+    if (int rc = set_window(p.win, window_host, n_rays, "sdn_field_encode")) return rc;
+    p.worklist = worklist;
+    if (worklist) {   // the two counters; the entries are all written by the kernel
+        if (hipMemsetAsync(worklist, 0, WL_HEAD * sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
+            return sdn::fail(SDN_ERR_LAUNCH, "sdn_field_encode: hipMemsetAsync failed");
+    }
     hipLaunchKernelGGL(encode_kernel, dim3(sdn::div_up(p.n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_encode");
 }
@@ -1585,7 +1702,8 @@ int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_d
 
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
-                  int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, sdn_stream_t stream) {
+                  int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
+                  const float *sky_avg, const int32_t *worklist, sdn_stream_t stream) {
     SDN_REQUIRE(feat && dist && label && rayflag && packed && consts && sky_c && net_out, "sdn_field_mlp: null pointer");
     SDN_REQUIRE(n_rays > 0 && num_samples > 0, "sdn_field_mlp: empty frame");
     SDN_REQUIRE(colour_terms == 2 || colour_terms == 3, "sdn_field_mlp: colour_terms must be 2 or 3");
@@ -1595,6 +1713,8 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     p.passes = passes;
     p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag; p.wpk = (const half8 *)packed;
     p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
+    p.sky_avg = sky_avg; p.worklist = worklist;
+    if (int rc = set_window(p.win, window_host, n_rays, "sdn_field_mlp")) return rc;
     p.R = n_rays; p.ns = num_samples;
     p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
     p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
@@ -1653,9 +1773,11 @@ static int sky_workgroups(int32_t n_rays, int32_t n_workgroups) {
 int32_t sdn_sky_partial_rows(int32_t n_rays, int32_t n_workgroups) { return n_rays > 0 ? 4 * sky_workgroups(n_rays, n_workgroups) : 0; }
 
 int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_partial, int32_t n_rays,
-                int32_t n_workgroups, sdn_stream_t stream) {
+                int32_t n_workgroups, float *sky_avg, uint32_t *counter, sdn_stream_t stream) {
     SDN_REQUIRE(raydirs && packed && consts && sky_c && sky_partial && n_rays > 0, "sdn_sky_mlp: bad argument");
+    SDN_REQUIRE((sky_avg == nullptr) == (counter == nullptr), "sdn_sky_mlp: sky_avg and counter go together");
     SkyParams p;
+    p.sky_avg = sky_avg; p.counter = counter;
     p.raydirs = raydirs; p.wpk = (const half8 *)packed; p.consts = consts; p.sky_c = sky_c; p.sky_partial = sky_partial;
     p.R = n_rays;
     p.n_tiles = sdn::div_up(n_rays, 32);

@@ -10,6 +10,26 @@ from . import capi
 
 _f2 = ctypes.c_float * 2
 _f3 = ctypes.c_float * 3
+_i5 = ctypes.c_int32 * 5
+
+
+class Window:
+    """Which rays of the frame-wide ray arrays (voxel_id [n_src,M], depth2 [2,n_src,M], raydirs [n_src,3], sky_c [n_src,64])
+    a field launch evaluates: ray (y, x) of a rows x cols window is source ray first + y * pitch + x.  The kernels read
+    through the window (include/sdnative.h, `window_host`), so no strided-slice copies are made on the host side."""
+
+    def __init__(self, n_src, pitch=0, first=0, rows=None, cols=0):
+        self.n_src, self.pitch, self.first, self.cols = int(n_src), int(pitch), int(first), int(cols)
+        self.rows = rows
+        self.n_rays = int(rows * cols) if cols else int(n_src)
+
+    @classmethod
+    def crop(cls, H0, W0, o):
+        """The H0 x W0 frame without its outer o rows / columns."""
+        return cls(H0 * W0, W0, o * W0 + o, H0 - 2 * o, W0 - 2 * o)
+
+    def host(self, ray0=0):
+        return _i5(self.n_src, self.pitch, self.first, self.cols, int(ray0))
 
 
 def _lib():
@@ -85,16 +105,23 @@ def _buffers(R, n_rays, ns, slot=0):
             dist=torch.empty(aux, dtype=torch.float32, device=R.dev),
             label=torch.empty(aux, dtype=torch.uint8, device=R.dev),
             rayflag=torch.empty(n_rays, dtype=torch.uint8, device=R.dev),
+            worklist=torch.empty(lib.sdn_field_worklist_elems(n_rays), dtype=torch.int32, device=R.dev),
             lin=torch.linspace(0, 1, ns + 3)[1:-1].contiguous().to(R.dev),  # mc_utils.py:120
         )
     return cache[key]
 
 
-def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None):
-    """u: None = deterministic sampling (inference); f32 [n_rays, ns + 1] uniform randoms (the caller's
+def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None, window=None, ray0=0, n_rays=None):
+    """Sample placement + hash-grid lookup for n_rays rays of the ray arrays vid / d2 / rd: all of them (window None), or
+    rays ray0 .. ray0 + n_rays - 1 of `window` (a Window over the frame-wide arrays).
+    u: None = deterministic sampling (inference); f32 [n_rays, ns + 1] uniform randoms (the caller's
     torch.rand(..., ns + 1) draw, mc_utils.py:121) = the training-time stratified sampling."""
     sc = R._fused_scene or prepare_scene(R)
-    n_rays = vid.shape[0]
+    if window is None:
+        window = Window(vid.shape[0])
+    assert vid.is_contiguous() and d2.is_contiguous() and rd.is_contiguous() and vid.shape[0] == window.n_src
+    if n_rays is None:
+        n_rays = window.n_rays - ray0
     buf = buf or _buffers(R, n_rays, ns)
     lin = buf["lin"]
     if u is not None:
@@ -110,7 +137,8 @@ def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None):
                                      lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M, ns,
                                      R.sample_depth, R.dists_scale,
                                      buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                     buf["rayflag"].data_ptr(), _stream(R.dev))
+                                     buf["rayflag"].data_ptr(), window.host(ray0), buf["worklist"].data_ptr(),
+                                     _stream(R.dev))
     capi.check(rc, "sdn_field_encode")
     return buf
 
@@ -134,44 +162,57 @@ def precision_profile(R):
     return ct, eps
 
 
-def _launch_mlp(R, buf, st, sky_c, net_out, n_rays, ns, passes=None):
+def _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, passes=None, window=None, ray0=0, worklist=True):
+    """sky_c [n_src,64] is indexed through `window` like the ray arrays; sky_avg dev f32 [64] (the frame mean, straight from
+    sky_kernel); net_out [n_rays,64] is local."""
     ct, eps = precision_profile(R)
+    assert sky_c.is_contiguous() and sky_avg.is_contiguous() and sky_avg.numel() == 64 and sky_avg.dtype == torch.float32
+    if window is None:
+        window = Window(sky_c.shape[0])
     with torch.cuda.device(R.dev):
         rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
                                   buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
                                   sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, ct, eps,
-                                  passes.data_ptr() if passes is not None else None, 0, _stream(R.dev))
+                                  passes.data_ptr() if passes is not None else None, 0, window.host(ray0),
+                                  sky_avg.data_ptr(), buf["worklist"].data_ptr() if worklist else None, _stream(R.dev))
     capi.check(rc, "sdn_field_mlp")
 
 
-def mlp_from(R, buf, sky_c, sky_avg, n_rays, ns):
+def mlp_from(R, buf, sky_c, sky_avg, n_rays, ns, window=None, worklist=True):
     """Second half of field_fused for an already encoded ray set (the pipelined trajectory path)."""
     st = R._fused_style or prepare_style(R)
-    st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
     net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
-    _launch_mlp(R, buf, st, sky_c, net_out, n_rays, ns)
+    _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, window=window, worklist=worklist)
     return net_out
 
 
+def _per_ray_feat_bytes(ns):
+    return _lib().sdn_field_feat_bytes(32, ns) // 32
+
+
 def single_chunk(n_rays, ns):
-    return n_rays * (_lib().sdn_field_feat_bytes(32, ns) // 32) <= FEATURE_BUFFER_BYTES
+    return n_rays * _per_ray_feat_bytes(ns) <= FEATURE_BUFFER_BYTES
 
 
-def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None):
-    """net_out [R,64] for intersections vid [R,M] / d2 [2,R,M] / raydirs rd [R,3].
+def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None, window=None):
+    """net_out [n,64] for the rays of `window` (default: all) of the intersections vid [n_src,M] / d2 [2,n_src,M] /
+    raydirs rd [n_src,3], sky features sky_c [n_src,64] and their frame mean sky_avg [64].
     Rays are independent, so very large frames (4K x 40 samples = 174 GB of features) go through in ray chunks that
     reuse one feature buffer; the headline frame (6.9 GB) is a single chunk."""
     st = R._fused_style or prepare_style(R)
-    n_rays = vid.shape[0]
-    st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
+    if window is None:
+        window = Window(vid.shape[0])
+    n_rays = window.n_rays
+    vid, d2, rd, sky_c = vid.contiguous(), d2.contiguous(), rd.contiguous(), sky_c.contiguous()
+    sky_avg = sky_avg.reshape(-1).to(torch.float32).contiguous()
     net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
-    per_ray = _lib().sdn_field_feat_bytes(32, ns) // 32
-    chunk = max(32, (FEATURE_BUFFER_BYTES // per_ray) // 32 * 32)     # whole 32-ray groups
+    chunk = max(32, (FEATURE_BUFFER_BYTES // _per_ray_feat_bytes(ns)) // 32 * 32)     # whole 32-ray groups
     for r0 in range(0, n_rays, chunk):
-        r1 = min(n_rays, r0 + chunk)
-        v, d, r_, s_ = vid[r0:r1].contiguous(), d2[:, r0:r1].contiguous(), rd[r0:r1].contiguous(), sky_c[r0:r1].contiguous()
-        buf = encode(R, v, d, r_, cam_ori, ns, u=u[r0:r1].contiguous() if u is not None else None)
-        _launch_mlp(R, buf, st, s_, net_out[r0:r1], r1 - r0, ns, passes[r0 // 32:] if passes is not None else None)
+        n = min(n_rays, r0 + chunk) - r0
+        uc = u[r0:r0 + n].contiguous() if u is not None else None
+        buf = encode(R, vid, d2, rd, cam_ori, ns, u=uc, window=window, ray0=r0, n_rays=n)
+        _launch_mlp(R, buf, st, sky_c, sky_avg, net_out[r0:r0 + n], n, ns, passes[r0 // 32:] if passes is not None else None,
+                    window=window, ray0=r0)
     return net_out
 
 
@@ -182,17 +223,17 @@ def time_mlp_kernel(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, reps=5):
     n = vid.numel() // R.M
     vid, d2, rd = vid.reshape(n, R.M).contiguous(), d2.reshape(2, n, R.M).contiguous(), rd.reshape(n, 3).contiguous()
     buf = encode(R, vid, d2, rd, cam_ori, ns)
-    st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
+    sky_avg = sky_avg.reshape(-1).to(torch.float32).contiguous()
     net_out = torch.empty((n, 64), dtype=torch.float32, device=R.dev)
     sky_c = sky_c.contiguous()
 
-    ms = _time_ms(lambda: _launch_mlp(R, buf, st, sky_c, net_out, n, ns), reps)
+    ms = _time_ms(lambda: _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n, ns), reps)
     hit = float((vid[:, 0] != 0).float().mean())
     # samples the kernel actually evaluates: it skips 32-ray groups (4 tiles of 8 consecutive rays) that hit nothing,
     # and the passes early termination removes
     g = torch.nn.functional.pad((vid[:, 0] != 0), (0, (-n) % 32)).view(-1, 32).any(dim=1)
     passes = torch.zeros(g.numel(), dtype=torch.uint8, device=R.dev)
-    _launch_mlp(R, buf, st, sky_c, net_out, n, ns, passes)
+    _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n, ns, passes)
     executed = int(passes.sum(dtype=torch.int64))
     nch = -(-ns // 4)
     return n * ns, ms, hit, dict(group_hit_fraction=float(g.float().mean()), evaluated_samples=executed * 128,
@@ -228,13 +269,18 @@ def prepare_sky(R):
 
 
 def sky_fused(R, rd):
-    """sky_c [R,64] and the frame mean sky_avg [1,64] for ray directions rd [R,3]."""
+    """sky_c [R,64] and the frame mean sky_avg [1,64] for ray directions rd [R,3] (the mean is finished inside the kernel by
+    its last workgroup: fixed summation order, no host-side reduction)."""
     sk = getattr(R, "_fused_sky", None) or prepare_sky(R)
     rd = rd.contiguous()
     n = rd.shape[0]
     sky_c = torch.empty((n, 64), dtype=torch.float32, device=R.dev)
     part = torch.empty((_lib().sdn_sky_partial_rows(n, 0), 64), dtype=torch.float32, device=R.dev)
+    sky_avg = torch.empty((1, 64), dtype=torch.float32, device=R.dev)
+    if "counter" not in sk:
+        sk["counter"] = torch.zeros(1, dtype=torch.int32, device=R.dev)     # the kernel leaves it at zero
     with torch.cuda.device(R.dev):
         capi.check(_lib().sdn_sky_mlp(rd.data_ptr(), sk["packed"].data_ptr(), sk["consts"].data_ptr(), sky_c.data_ptr(),
-                                      part.data_ptr(), n, 0, _stream(R.dev)), "sdn_sky_mlp")
-    return sky_c, (part.sum(dim=0, dtype=torch.float64) / n).to(torch.float32).reshape(1, 64)
+                                      part.data_ptr(), n, 0, sky_avg.data_ptr(), sk["counter"].data_ptr(), _stream(R.dev)),
+                   "sdn_sky_mlp")
+    return sky_c, sky_avg

@@ -19,6 +19,7 @@ are folded once per style code instead of once per tile.
 """
 import json
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -78,7 +79,11 @@ class Renderer:
         if self.volume.is_cuda:
             ops.voxel_occupancy(self.volume)   # built here, on the caller's stream, before any side-stream ray casting
         w = self.w
-        with torch.no_grad():  # ConditionalHashGrid.forward, layers.py:40-55
+        # (deterministic convolution algorithms: global_enc feeds every sample of every frame, and every rank of a sharded
+        # trajectory computes it for itself -- MIOpen's default solver choice is not reproducible from call to call)
+        with torch.no_grad(), warnings.catch_warnings(), \
+                torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):  # ConditionalHashGrid.forward, layers.py:40-55
+            warnings.simplefilter("ignore")
             h = _lrelu(F.conv2d(scene.current_height_map.to(self.dev), w["world_encoder.hconv_head.weight"],
                                 w["world_encoder.hconv_head.bias"], stride=2, padding=1))
             s = _lrelu(F.conv2d(scene.current_semantic_map.to(self.dev), w["world_encoder.sconv_head.weight"],
@@ -269,6 +274,36 @@ class Renderer:
             sky_avg = sky_c.mean(dim=0, keepdim=True)
             B, ms_enc, per_sample, kernel = fused.time_encode_kernel(self, vid, d2, rd, cam_ori, num_samples)
             _, ms_mlp, hit, ev = fused.time_mlp_kernel(self, vid, d2, rd, cam_ori, sky_c, sky_avg, num_samples)
+        return self.roofline_records(B, ms_enc, ms_mlp, hit, ev, kernel, hbm_peak_gbps, mfma_peak_tflops,
+                                     "HIP events around 5 back-to-back launches of each kernel on the whole padded frame, "
+                                     "outside the timed region")
+
+    def field_work(self, poses, resolution_hw, num_samples, apron="minimal"):
+        """What the field kernels of the fused frame loop process for these poses, averaged per frame (outside any timed
+        region: one ray cast per pose): samples per launch, fraction of rays that hit something, and the samples
+        mlp_kernel evaluates (it visits only 32-ray groups with a hit; early termination must be off)."""
+        from . import fused
+        crop = self.pad // 2
+        o = crop - CNN_HALO if (apron == "minimal" and crop > CNN_HALO) else 0
+        nch = -(-num_samples // 4)
+        B = hits = groups = evald = 0.0
+        with torch.no_grad():
+            for pose in poses:
+                vid, _, _, (H0, W0) = self.cast_rays(pose, resolution_hw)
+                hit = (vid.view(H0, W0, self.M)[o:H0 - o, o:W0 - o, 0] != 0).reshape(-1)
+                n = hit.numel()
+                g = torch.nn.functional.pad(hit, (0, (-n) % 32)).view(-1, 32).any(dim=1)
+                B += n * num_samples
+                hits += float(hit.float().mean())
+                groups += float(g.float().mean())
+                evald += int(g.sum()) * 32 * nch * 4
+        k = max(1, len(poses))
+        return B / k, hits / k, dict(group_hit_fraction=groups / k, evaluated_samples=evald / k, passes_skipped_by_termination=0)
+
+    def roofline_records(self, B, ms_enc, ms_mlp, hit, ev, kernel, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0, timing=""):
+        """(field-MLP record, grid-sampler record) from per-launch work (B samples, hit fraction, evaluated samples in
+        `ev`) and average launch durations."""
+        from . import fused
         traffic, traffic_src = _profiled_traffic()
         ct, eps = fused.precision_profile(self)
         # ---- grid sampler (encode_kernel).  SURVEY 8(d): effective gather bandwidth = samples x 16 404 B / time.  The
@@ -280,7 +315,7 @@ class Renderer:
         coll = n_gather * (4096 + 20 + 512) / (ms_enc * 1e-3) / 1e9   # bytes the kernel really moves at L2 level
         dram = traffic.get("encode_kernel")
         grid = {"bound": "l2", "kernel": kernel, "achieved": coll, "peak": L2_PEAK_GBPS, "unit": "GB/s",
-                "frac": coll / L2_PEAK_GBPS, "avg_launch_ms": ms_enc, "samples_per_launch": B,
+                "frac": coll / L2_PEAK_GBPS, "avg_launch_ms": ms_enc, "samples_per_launch": B, "timing": timing,
                 "samples_with_gathers": n_gather,
                 "effective_GBps": eff, "effective_bytes_per_sample": 16404, "effective_over_hbm_peak": eff / hbm_peak_gbps,
                 "collapsed_GBps": coll, "collapsed_bytes_per_sample": 4096 + 20 + 512,
@@ -304,6 +339,7 @@ class Renderer:
                "avg_launch_ms": ms_mlp, "ray_hit_fraction": hit, "group_hit_fraction": ev["group_hit_fraction"],
                "early_termination_eps": eps, "passes_skipped_by_termination": ev["passes_skipped_by_termination"],
                "issued_over_algorithmic": issued, "issued_frac_of_peak": ach_m * issued / mfma_peak_tflops,
+               "timing": timing,
                "achieved_counting_skipped_samples": B * 754176 / (ms_mlp * 1e-3) / 1e12,
                "note": "achieved = samples evaluated x 754 176 FLOP / launch time (skipped sky groups are not counted as "
                        "work); the kernel issues `issued_over_algorithmic` f16 MFMAs per algorithmic product (hi*hi + "
@@ -400,14 +436,14 @@ class Renderer:
                 sky_avg = sky_c.mean(dim=0, keepdim=True)    # full-frame mean, scenedreamer.py:592-598
             ev.mark("sky")
             crop = self.pad // 2
+            window = None
             if mode == "fused" and cnn and apron == "minimal" and crop > CNN_HALO:
-                o = crop - CNN_HALO     # rows / columns of the padded frame that cannot influence the cropped image
-                vid = vid.view(Hp, Wp, self.M)[o:Hp - o, o:Wp - o].reshape(-1, self.M)
-                d2 = d2.view(2, Hp, Wp, self.M)[:, o:Hp - o, o:Wp - o].reshape(2, -1, self.M)
-                rd = rd.view(Hp, Wp, 3)[o:Hp - o, o:Wp - o].reshape(-1, 3)
-                sky_c = sky_c.view(Hp, Wp, 64)[o:Hp - o, o:Wp - o].reshape(-1, 64)
+                # rows / columns of the padded frame that cannot influence the cropped image are not evaluated: the field
+                # kernels read the frame-wide ray arrays through a window (no strided-slice copies)
+                from . import fused
+                o = crop - CNN_HALO
+                window = fused.Window.crop(Hp, Wp, o)
                 Hp, Wp, crop = Hp - 2 * o, Wp - 2 * o, CNN_HALO
-                R = Hp * Wp
             if mode == "unfused":
                 outs = []
                 for r0 in range(0, R, ray_chunk):
@@ -417,7 +453,7 @@ class Renderer:
                 net_out = torch.cat(outs, dim=0)
             elif mode == "fused":
                 from . import fused
-                net_out = fused.field_fused(self, vid, d2, rd, cam_ori, sky_c, sky_avg, num_samples)
+                net_out = fused.field_fused(self, vid, d2, rd, cam_ori, sky_c, sky_avg, num_samples, window=window)
             else:
                 raise ValueError(mode)
             net_out = net_out.view(1, Hp, Wp, 64)
@@ -441,12 +477,15 @@ class Renderer:
             return img
 
 
-def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="fused", apron="minimal", **kw):
+def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="fused", apron="minimal", probe=None, **kw):
     """Generator over the frames of a trajectory, software-pipelined over two streams: the front half of frame i+1
     (ray casting, sky MLP, sample encode) is issued on a second stream while the back half of frame i (field MLP, render
     CNN) runs.  rvip_kernel (20 registers, no LDS) co-resides with the one-workgroup-per-CU MFMA kernels; the sky and
     encode kernels fill the CUs that idle at the tails and launch boundaries of the MFMA kernels.  Images are bit-identical
-    to render_frame (tests/test_fullsize_gpu.py)."""
+    to render_frame (tests/test_fullsize_gpu.py).
+    probe: optional dict; gets lists of (start, end) timing events around the dominant kernels' launches, recorded on the
+    stream they are launched on ("mlp_kernel": main stream, "encode_kernel": side stream) -- bench.py's roofline record is
+    computed from the launches of the timed region itself."""
     from . import fused
     poses = list(poses)
     if not poses:
@@ -470,15 +509,20 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
             out = (vid, d2, rd, res)
             if deep:
                 H0, W0 = res
-                sky_c, sky_avg = fused.sky_fused(self, rd.view(H0 * W0, 3))
-                vid = vid.view(H0, W0, self.M)[o:H0 - o, o:W0 - o].reshape(-1, self.M).contiguous()
-                d2 = d2.view(2, H0, W0, self.M)[:, o:H0 - o, o:W0 - o].reshape(2, -1, self.M).contiguous()
-                rdc = rd.view(H0, W0, 3)[o:H0 - o, o:W0 - o].reshape(-1, 3).contiguous()
-                sky_c = sky_c.view(H0, W0, 64)[o:H0 - o, o:W0 - o].reshape(-1, 64).contiguous()
-                buf = fused.encode(self, vid, d2, rdc, torch.as_tensor(pose[0], dtype=torch.float32), num_samples,
-                                   fused._buffers(self, vid.shape[0], num_samples, slot))
-                out = (buf, sky_c, sky_avg, vid.shape[0])
-                keep = (sky_c, sky_avg)
+                n0 = H0 * W0
+                vid, d2, rd = vid.view(n0, self.M), d2.view(2, n0, self.M), rd.view(n0, 3)
+                sky_c, sky_avg = fused.sky_fused(self, rd)
+                win = fused.Window.crop(H0, W0, o)      # the kernels read the frame-wide arrays through the window
+                if probe is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
+                buf = fused.encode(self, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), num_samples,
+                                   fused._buffers(self, win.n_rays, num_samples, slot), window=win)
+                if probe is not None:
+                    e1.record(side)
+                    probe.setdefault("encode_kernel", []).append((e0, e1))
+                out = (buf, sky_c, sky_avg, win)
+                keep = (sky_c, sky_avg)     # vid / d2 / rd are only read on the side stream (by encode)
             else:
                 keep = out[:3]
             done = torch.cuda.Event()
@@ -495,9 +539,15 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
         if not deep:
             yield self.render_frame(pose, resolution_hw, num_samples, mode=mode, apron=apron, _precast=cur, **kw)
             continue
-        buf, sky_c, sky_avg, n = cur
+        buf, sky_c, sky_avg, win = cur
         with torch.no_grad():
-            net_out = fused.mlp_from(self, buf, sky_c, sky_avg, n, num_samples).view(1, Hp, Wp, 64)
+            if probe is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(main)
+            net_out = fused.mlp_from(self, buf, sky_c, sky_avg.reshape(-1), win.n_rays, num_samples, window=win).view(1, Hp, Wp, 64)
+            if probe is not None:
+                e1.record(main)
+                probe.setdefault("mlp_kernel", []).append((e0, e1))
             if getattr(self, "_mfma_cnn", None) is None:
                 from .cnn import MfmaCNN
                 self._mfma_cnn = MfmaCNN(self, getattr(self, "cnn_terms3x3", None))

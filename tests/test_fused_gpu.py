@@ -201,3 +201,81 @@ def test_fused_encode_with_stochastic_sampling(renderer, weights_full, lut):
     det = float(np.abs(ref.numpy() - g["net_out"]).max())
     print(f"stochastic sampling, fused vs oracle: max abs err {err:.2e} (stochastic vs deterministic output differs by {det:.2e})")
     assert err < 1e-3 and det > 1e-3
+
+
+def _frame(renderer, hw=(72, 104), pose_i=3):
+    from scenedreamer_amd import camera
+    poses = camera.eval_camera_poses(renderer.scene, maxstep=8)
+    pose = poses[pose_i]
+    vid, d2, rd, (H0, W0) = renderer.cast_rays(pose, hw)
+    n = H0 * W0
+    return pose, vid.view(n, renderer.M), d2.view(2, n, renderer.M), rd.view(n, 3), H0, W0
+
+
+def test_sky_mean_finished_in_kernel(renderer):
+    """The frame mean of the sky features is added up by sky_kernel's last workgroup (fixed order, double): equal to a
+    float64 column mean of the sky_c it wrote, identical across launches (the arrival counter resets itself), and correct
+    for ray counts that leave workgroups / waves partly or wholly idle."""
+    from scenedreamer_amd import fused
+    renderer.set_style_code(golden("field_a.npz")["z"])
+    _, _, _, rd, _, _ = _frame(renderer)
+    for n in (rd.shape[0], 33, 128 * 256 + 5):
+        r = rd[:n] if n <= rd.shape[0] else torch.cat([rd] * (n // rd.shape[0] + 1))[:n]
+        sky_c, avg = fused.sky_fused(renderer, r)
+        ref = (sky_c.sum(dim=0, dtype=torch.float64) / n).to(torch.float32)
+        assert (avg.reshape(-1) - ref).abs().max().item() < 1e-6
+        sky_c2, avg2 = fused.sky_fused(renderer, r)
+        assert torch.equal(avg, avg2) and torch.equal(sky_c, sky_c2)
+
+
+def test_ray_window_equals_sliced_copies(renderer):
+    """encode / mlp reading the frame-wide ray arrays through a window (cropped apron, chunk offsets) produce the bits
+    the same kernels produce on strided-slice COPIES of those rays; the work list (hit groups dealt round-robin)
+    produces the bits of the static group loop."""
+    from scenedreamer_amd import fused
+    renderer.set_style_code(golden("field_a.npz")["z"])
+    pose, vid, d2, rd, H0, W0 = _frame(renderer)
+    ns, o, M = 12, 11, renderer.M
+    sky_c, sky_avg = fused.sky_fused(renderer, rd)
+    win = fused.Window.crop(H0, W0, o)
+    # the copies the host side used to make
+    cv = vid.view(H0, W0, M)[o:H0 - o, o:W0 - o].reshape(-1, M).contiguous()
+    cd = d2.view(2, H0, W0, M)[:, o:H0 - o, o:W0 - o].reshape(2, -1, M).contiguous()
+    cr = rd.view(H0, W0, 3)[o:H0 - o, o:W0 - o].reshape(-1, 3).contiguous()
+    cs = sky_c.view(H0, W0, 64)[o:H0 - o, o:W0 - o].reshape(-1, 64).contiguous()
+    assert win.n_rays == cv.shape[0]
+    ori = torch.as_tensor(pose[0], dtype=torch.float32)
+    b_copy = {k: v.clone() for k, v in fused.encode(renderer, cv, cd, cr, ori, ns).items() if k != "worklist"}
+    b_win = fused.encode(renderer, vid, d2, rd, ori, ns, window=win)
+    hit_rows = (cv[:, 0] != 0).view(-1, 1)
+    for k in ("dist", "label", "rayflag"):
+        assert torch.equal(b_copy[k], b_win[k]), k
+    # features are only defined for tiles (8 rays) with a hit: compare those
+    tiles = torch.nn.functional.pad(hit_rows.view(-1), (0, (-hit_rows.numel()) % 8)).view(-1, 8).any(dim=1)
+    fa, fb = b_copy["feat"].view(tiles.numel(), -1)[tiles], b_win["feat"].view(tiles.numel(), -1)[tiles]
+    assert torch.equal(fa, fb)
+    # work list: every group exactly once, hit groups in front
+    wl = b_win["worklist"].cpu().numpy()
+    n_groups = wl.size - 2
+    g_hit = torch.nn.functional.pad(hit_rows.view(-1), (0, (-hit_rows.numel()) % 32)).view(-1, 32).any(dim=1).cpu().numpy()
+    assert wl[0] == g_hit.sum() and wl[0] + wl[1] == n_groups
+    assert sorted(wl[2:2 + wl[0]]) == list(np.nonzero(g_hit)[0]) and sorted(wl[2 + wl[0]:]) == list(np.nonzero(~g_hit)[0])
+    st = renderer._fused_style or fused.prepare_style(renderer)
+    outs = {}
+    for tag, (buf, sc, w, use_wl) in {"copy": (b_win, cs, None, False), "window": (b_win, sky_c, win, False),
+                                      "worklist": (b_win, sky_c, win, True)}.items():
+        no = torch.full((win.n_rays, 64), float("nan"), device="cuda")
+        fused._launch_mlp(renderer, buf, st, sc, sky_avg.reshape(-1), no, win.n_rays, ns, window=w, worklist=use_wl)
+        outs[tag] = no
+    assert torch.equal(outs["copy"], outs["window"]) and torch.equal(outs["copy"], outs["worklist"])
+    assert torch.isfinite(outs["copy"]).all()
+    # chunked evaluation (ray0 offsets into the window) == one launch
+    whole = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win)
+    assert torch.equal(whole, outs["copy"])
+    old = fused.FEATURE_BUFFER_BYTES
+    try:
+        fused.FEATURE_BUFFER_BYTES = fused._per_ray_feat_bytes(ns) * 32 * 37     # 37 groups per chunk
+        chunked = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win)
+    finally:
+        fused.FEATURE_BUFFER_BYTES = old
+    assert torch.equal(chunked, whole)

@@ -31,9 +31,7 @@ with torch.no_grad():
     f2, c2, _ = camera.frame_intrinsics(pose2[3], (540, 960), 30)
 
     def mlp():
-        capi.check(capi.lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                            buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
-                                            sky_c.data_ptr(), net_out.data_ptr(), n, ns, 0, capi.current_stream(dev)))
+        fused._launch_mlp(R, buf, st, sky_c, sky_avg.reshape(-1), net_out, n, ns)
 
     def front():
         v, dd, r = ops.ray_voxel_intersection_perspective(scene.voxel_t, pose2[0], pose2[1], pose2[2], f2, c2, cam_res, R.M)

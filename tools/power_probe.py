@@ -25,9 +25,7 @@ with torch.no_grad():
     cnn = MfmaCNN(R)
     x = torch.rand(1, cam_res[0], cam_res[1], 64, device=dev) * 2 - 1
     fns = {
-        "mlp": lambda: capi.check(capi.lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                                            buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
-                                                            sky_c.data_ptr(), net_out.data_ptr(), n, 24, 0, capi.current_stream(dev))),
+        "mlp": lambda: fused._launch_mlp(R, buf, st, sky_c, sky_avg.reshape(-1), net_out, n, 24),
         "conv": lambda: cnn(x),
         "encode": lambda: fused.encode(R, vid, d2, rd, ori, 24, buf),
     }
