@@ -161,8 +161,6 @@ size_t sdn_field_consts_floats(void);
 int sdn_field_const_offset(int which);
 size_t sdn_field_feat_bytes(int32_t n_rays, int32_t num_samples);
 size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples);
-/* int32 elements of the optional work list encode writes for mlp: [hit groups][other groups][one entry per 32-ray group] */
-size_t sdn_field_worklist_elems(int32_t n_rays);
 
 /* embeddings dev f32 [sO,8]; offsets_host int32[L+1]; genc_host f32[2] = world_encoder output;
  * table3 dev f32 [16, T, 8] (T = rows per level) */
@@ -182,15 +180,12 @@ int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const 
  *   {n_src, pitch, first, cols, ray0}: the arrays hold n_src rays (the whole padded frame the ray marcher wrote, as the
  *   reference's per-frame voxlib call does, scenedreamer.py:576-590) and local ray r is ray w = ray0 + r of a window of
  *   `cols` columns whose ray (y, x) is source ray first + y * pitch + x (cols = 0: source ray = ray0 + r).  Outputs
- *   (feat, dist, label, rayflag) and u_dev are indexed by the LOCAL ray.
- * worklist: NULL, or dev int32 [sdn_field_worklist_elems(n_rays)], filled for sdn_field_mlp: the 32-ray groups with a
- *   ray that hits something (count in [0], indices from [2] on) and those without (count in [1], indices from the end). */
+ *   (feat, dist, label, rayflag) and u_dev are indexed by the LOCAL ray. */
 int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
                      int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
-                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, int32_t *worklist,
-                     sdn_stream_t stream);
+                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, sdn_stream_t stream);
 /* mc_utils.sample_depth_batched (imaginaire/model_utils/gancraft/mc_utils.py:82-151, use_box_boundaries = False) as an op:
  * depth2 dev f32 [2,R,M] -> rand_depth, new_dists dev f32 [R, n_points-1], idx dev i64 [R, n_points-1] (raw values: NaN
  * depths of rays without a hit are left for the caller to zero, scenedreamer.py:350-352).  lin_dev / u_dev as above with
@@ -205,12 +200,14 @@ int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_d
  * window_host: as for sdn_field_encode; it applies to sky_c (indexed by the SOURCE ray: the sky MLP covers the whole
  *   padded frame), net_out is indexed by the local ray.
  * sky_avg: NULL (the value at const offset 5 is used) or dev f32 [64], the frame mean sdn_sky_mlp finished.
- * worklist: NULL (every group is visited, groups whose 32 rays hit nothing are skipped) or the list the matching
- *   sdn_field_encode call wrote (hit groups are dealt round-robin to the persistent workgroups: equal shares). */
+ * ticket: NULL (workgroup b of G evaluates the 32-ray groups b, b + G, ...; groups whose rays all miss are skipped) or dev
+ *   int32[2], ZERO before the first launch and left zero by every launch: after two static rounds the persistent
+ *   workgroups draw their groups from this counter, so none idles at the end because its share was mostly sky.  One
+ *   launch at a time per ticket buffer.  net_out does not depend on the schedule. */
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
                   int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
-                  const float *sky_avg, const int32_t *worklist, sdn_stream_t stream);
+                  const float *sky_avg, int32_t *ticket, sdn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Render CNN: the convolutions of RenderCNN (imaginaire/generators/gancraft_base.py:175-225, forward :202-225) on MFMA

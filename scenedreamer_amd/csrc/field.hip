@@ -89,12 +89,6 @@ struct RayWindow {
     }
 };
 
-// Work list of the field MLP, filled by encode_kernel (one workgroup = 4 ray tiles = one 32-ray group of mlp_kernel):
-// wl[0] = number of groups with at least one ray that hits something, their indices in wl[2 .. 2 + wl[0]) (any order);
-// wl[1] = number of groups that hit nothing, their indices from the END of the array backwards.  The persistent MLP
-// workgroups take the hit groups round-robin, so every workgroup gets the same number of them to within one
-// (a static g % 256 assignment of ALL groups left workgroups whose share was mostly sky idle at the end: 2-4 %).
-constexpr int WL_HEAD = 2;
 
 struct EncParams {
     const int32_t *voxel_id;   // [R, M]
@@ -115,7 +109,6 @@ struct EncParams {
     const float *u;            // dev [R][ns+1] uniform randoms of the training-time stratified sampling, or nullptr
     const float *scales;       // dev [16]    per-level scale, exp2f(l*S)*H-1 evaluated on the host
     RayWindow win;             // where ray r of this launch lives in voxel_id / depth2 / raydirs
-    int32_t *worklist;         // optional [2 + n_groups]: see Worklist below
 };
 
 struct MlpParams {
@@ -132,7 +125,9 @@ struct MlpParams {
     uint8_t *passes;           // optional [ceil(n_tiles / 4)]: passes every 32-ray group went through (tests / bench)
     RayWindow win;             // sky_c is indexed with the SOURCE ray (it covers the whole padded frame)
     const float *sky_avg;      // optional dev [64]: frame mean of sky_c (else the value inside `consts`)
-    const int32_t *worklist;   // optional: groups to evaluate, written by encode_kernel
+    int32_t *ticket;           // optional dev int32[2], zero before the first launch (the kernel leaves it zero): the
+                               // persistent workgroups draw their 32-ray groups from it instead of taking every
+                               // gridDim.x-th one (a static share that is mostly sky leaves its workgroup idle at the end)
 };
 
 // =====================================================================================================
@@ -332,13 +327,12 @@ __device__ __forceinline__ float normalise_coord(float wc, float delim) {
 }
 
 __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
-    __shared__ int s_hit[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x * 4 + wave;
-    const bool tile_ok = tile < p.n_tiles;
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= p.n_tiles) return;
     const int h = lane >> 5, j = lane & 31;
     const int ray = tile * RAYS_PER_TILE + (j >> 2);
-    const bool ray_ok = tile_ok && ray < p.R;
+    const bool ray_ok = ray < p.R;
     const int rl = ray_ok ? ray : p.R - 1;      // local ray (index into u / rayflag)
     const int rr = p.win.src(rl);               // the same ray in the source arrays
     const size_t RS = (size_t)p.win.n_src;
@@ -362,16 +356,6 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
     // (the MLP kernel reads whatever is there and discards the result by selection, not multiplication).
     const bool use_feat = ray_ok && rb.id[0] != 0;
     const bool tile_dead = !__any(use_feat);
-    if (p.worklist) {   // this workgroup's 32-ray group goes on the MLP's work list (hit groups from the front, others from the back)
-        if (lane == 0) s_hit[wave] = tile_dead ? 0 : 1;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int n_groups = (p.n_tiles + 3) >> 2;
-            if (s_hit[0] | s_hit[1] | s_hit[2] | s_hit[3]) p.worklist[WL_HEAD + atomicAdd(&p.worklist[0], 1)] = blockIdx.x;
-            else p.worklist[WL_HEAD + n_groups - 1 - atomicAdd(&p.worklist[1], 1)] = blockIdx.x;
-        }
-    }
-    if (!tile_ok) return;
 
     for (int ch = 0; ch < p.nch; ch++) {
         const int sidx = ch * SAMP_PER_STEP + (j & 3);
@@ -1035,14 +1019,6 @@ __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], h
     out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, bias_pend, h, part);
 }
 
-// wave-uniform 4-byte load through the scalar cache (an ordinary load here would make hipcc's wait insertion drain the
-// weight ring's DMA queue -- vmcnt(0) -- wherever the value is used)
-__device__ __forceinline__ int sload(const int32_t *ptr) {
-    int v;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(ptr) : "memory");
-    return v;
-}
-
 // CT = number of split terms of the colour layers fc_5 / fc_6 (3, or 2 = without the Whi.Xlo products)
 template <int DBG, int CT>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
@@ -1086,13 +1062,14 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     unsigned n_pass = 0;
     if constexpr (DBG & 128) t_kernel0 = __builtin_readcyclecounter();
     const int n_groups = (p.n_tiles + 3) >> 2;
-    // With a work list (written by encode_kernel) the loop runs over the groups that hit something, then over the ones
-    // that do not (sky blend only); without one over all groups, a group being skipped when none of its rays hits.
-    const int n_hit = p.worklist ? sload(p.worklist) : n_groups;
-    const int n_items = p.worklist ? n_hit + sload(p.worklist + 1) : n_groups;
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        // item -> group: hit groups from the front of the list, the others from its end
-        const int grp = p.worklist ? sload(p.worklist + WL_HEAD + (it < n_hit ? it : n_groups - 1 - (it - n_hit))) : it;
+    // Group schedule.  Static: workgroup b takes groups b, b + G, b + 2G, ... (G = gridDim.x).  With a ticket counter the
+    // first TWO rounds are static and every later group is drawn from the counter one group AHEAD of its use (the draw
+    // of group n+2 is issued at the start of group n and read at the start of group n+1, so its latency is never
+    // waited for, and the group after the current one is always known: its first pass is prefetched during the current
+    // group's last).  Groups are independent, so net_out does not depend on the schedule.
+    volatile int *flags = reinterpret_cast<volatile int *>(lds + LDS_FLAGS);
+    int grp = blockIdx.x, grp_next = blockIdx.x + (int)gridDim.x;
+    while (grp < n_groups) {
         const int tile = grp * 4 + wave;
         const bool tile_ok = tile < p.n_tiles;
         const int tile_s = grp * 4 + r.wave;              // the same as scalars (r.wave went through readfirstlane)
@@ -1100,22 +1077,20 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         const int ray = tile * RAYS_PER_TILE + (j >> 2);
         const bool ray_ok = tile_ok && ray < p.R;
         const uint8_t flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
-        volatile int *flags = reinterpret_cast<volatile int *>(lds + LDS_FLAGS);
-        bool grp_hit;
-        if (p.worklist) {
-            grp_hit = it < n_hit;
-        } else {
-            const bool any_hit = __any(!(flag & 1));
-            // workgroup-uniform decision: skip the group when none of its 32 rays hits anything
-            if (lane == 0) flags[wave] = any_hit ? 1 : 0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // readfirstlane makes the decision provably uniform: otherwise every loop-carried ring counter / pointer is
-            // classified divergent, lives in VGPRs (spills!) and the DMA cannot use scalar addressing
-            grp_hit = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // the next group rewrites the flags only after everyone has read them
-        }
+        int drawn = grp_next + (int)gridDim.x;            // the group after next: static stride, or ...
+        if (p.ticket && threadIdx.x == 0) drawn = 2 * (int)gridDim.x + atomicAdd(p.ticket, 1);   // ... the next undrawn one
+        const bool any_hit = __any(!(flag & 1));
+        // workgroup-uniform decisions: skip the group when none of its 32 rays hits anything; everybody learns the draw
+        if (lane == 0) flags[wave] = any_hit ? 1 : 0;
+        if (threadIdx.x == 0) flags[4] = drawn;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // readfirstlane makes the decisions provably uniform: otherwise every loop-carried ring counter / pointer is
+        // classified divergent, lives in VGPRs (spills!) and the DMA cannot use scalar addressing
+        const bool grp_hit = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+        const int grp_next2 = __builtin_amdgcn_readfirstlane(flags[4]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // the next group rewrites the flags only after everyone has read them
 
         float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float carry = 0.f, tsum = 0.f;
@@ -1209,14 +1184,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 long tn = tc_s + 1;
                 bool has_next = tile_ok_s;
                 if (ch + 1 == p.nch) {
-                    // first step of this wave's tile in the workgroup's next group (work list: its next HIT group)
-                    const int it2 = it + (int)gridDim.x;
-                    int tile2 = p.n_tiles;
-                    if (p.worklist) {
-                        if (it2 < n_hit) tile2 = sload(p.worklist + WL_HEAD + it2) * 4 + r.wave;
-                    } else {
-                        tile2 = it2 * 4 + r.wave;
-                    }
+                    // first step of this wave's tile in the workgroup's next group (wasted if that group hits nothing)
+                    const int tile2 = grp_next * 4 + r.wave;
                     has_next = tile2 < p.n_tiles;
                     tn = (long)tile2 * p.nch;
                 }
@@ -1311,10 +1280,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 *reinterpret_cast<float4 *>(p.net_out + (size_t)ray * OUTC + f0) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
+        grp = grp_next;
+        grp_next = grp_next2;
     }
     // the ring runs DMA_AHEAD slots ahead of the last pass: let it land before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // the last workgroup to leave resets the ticket counter for the next launch
+    if (p.ticket && threadIdx.x == 0 && atomicAdd(p.ticket + 1, 1) == (int)gridDim.x - 1) {
+        p.ticket[0] = 0;
+        p.ticket[1] = 0;
+    }
     if constexpr (DBG & 128) {   // timing experiment: (input-staging cycles, total cycles, passes) of this wave into net_out
         if (lane == 0) {
             float *o = p.net_out + (size_t)(blockIdx.x * 4 + wave) * OUTC;
@@ -1644,16 +1620,11 @@ static int set_window(RayWindow &w, const int32_t *window_host, int32_t n_rays, 
     return 0;
 }
 
-size_t sdn_field_worklist_elems(int32_t n_rays) {
-    return (size_t)WL_HEAD + (size_t)sdn::div_up(sdn::div_up(n_rays, RAYS_PER_TILE), 4);
-}
-
 int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
                      int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
-                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, int32_t *worklist,
-                     sdn_stream_t stream) {
+                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, sdn_stream_t stream) {
     SDN_REQUIRE(voxel_id && depth2 && raydirs && lut1024 && table3 && scales_dev && genc_host && cam_ori_host &&
                     voxel_dims_host && lin_dev && feat && dist && label && rayflag,
                 "sdn_field_encode: null pointer");
@@ -1679,11 +1650,6 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
     p.u = u_dev;
     p.scales = scales_dev;
     if (int rc = set_window(p.win, window_host, n_rays, "sdn_field_encode")) return rc;
-    p.worklist = worklist;
-    if (worklist) {   // the two counters; the entries are all written by the kernel
-        if (hipMemsetAsync(worklist, 0, WL_HEAD * sizeof(int32_t), (hipStream_t)stream) != hipSuccess)
-            return sdn::fail(SDN_ERR_LAUNCH, "sdn_field_encode: hipMemsetAsync failed");
-    }
     hipLaunchKernelGGL(encode_kernel, dim3(sdn::div_up(p.n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_encode");
 }
@@ -1703,7 +1669,7 @@ int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_d
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
                   int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
-                  const float *sky_avg, const int32_t *worklist, sdn_stream_t stream) {
+                  const float *sky_avg, int32_t *ticket, sdn_stream_t stream) {
     SDN_REQUIRE(feat && dist && label && rayflag && packed && consts && sky_c && net_out, "sdn_field_mlp: null pointer");
     SDN_REQUIRE(n_rays > 0 && num_samples > 0, "sdn_field_mlp: empty frame");
     SDN_REQUIRE(colour_terms == 2 || colour_terms == 3, "sdn_field_mlp: colour_terms must be 2 or 3");
@@ -1713,7 +1679,7 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
     p.passes = passes;
     p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag; p.wpk = (const half8 *)packed;
     p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
-    p.sky_avg = sky_avg; p.worklist = worklist;
+    p.sky_avg = sky_avg; p.ticket = ticket;
     if (int rc = set_window(p.win, window_host, n_rays, "sdn_field_mlp")) return rc;
     p.R = n_rays; p.ns = num_samples;
     p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);

@@ -105,7 +105,6 @@ def _buffers(R, n_rays, ns, slot=0):
             dist=torch.empty(aux, dtype=torch.float32, device=R.dev),
             label=torch.empty(aux, dtype=torch.uint8, device=R.dev),
             rayflag=torch.empty(n_rays, dtype=torch.uint8, device=R.dev),
-            worklist=torch.empty(lib.sdn_field_worklist_elems(n_rays), dtype=torch.int32, device=R.dev),
             lin=torch.linspace(0, 1, ns + 3)[1:-1].contiguous().to(R.dev),  # mc_utils.py:120
         )
     return cache[key]
@@ -137,8 +136,7 @@ def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None, window=None, ray0=0, n
                                      lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M, ns,
                                      R.sample_depth, R.dists_scale,
                                      buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                     buf["rayflag"].data_ptr(), window.host(ray0), buf["worklist"].data_ptr(),
-                                     _stream(R.dev))
+                                     buf["rayflag"].data_ptr(), window.host(ray0), _stream(R.dev))
     capi.check(rc, "sdn_field_encode")
     return buf
 
@@ -162,27 +160,30 @@ def precision_profile(R):
     return ct, eps
 
 
-def _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, passes=None, window=None, ray0=0, worklist=True):
+def _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, passes=None, window=None, ray0=0, dynamic=True):
     """sky_c [n_src,64] is indexed through `window` like the ray arrays; sky_avg dev f32 [64] (the frame mean, straight from
-    sky_kernel); net_out [n_rays,64] is local."""
+    sky_kernel); net_out [n_rays,64] is local.  dynamic: the persistent workgroups draw their 32-ray groups from a
+    ticket counter (one per renderer: launches of one renderer are serialized on its stream) instead of a static stride."""
     ct, eps = precision_profile(R)
     assert sky_c.is_contiguous() and sky_avg.is_contiguous() and sky_avg.numel() == 64 and sky_avg.dtype == torch.float32
     if window is None:
         window = Window(sky_c.shape[0])
+    if "ticket" not in st:
+        st["ticket"] = torch.zeros(2, dtype=torch.int32, device=R.dev)      # the kernel leaves it at zero
     with torch.cuda.device(R.dev):
         rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
                                   buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
                                   sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, ct, eps,
                                   passes.data_ptr() if passes is not None else None, 0, window.host(ray0),
-                                  sky_avg.data_ptr(), buf["worklist"].data_ptr() if worklist else None, _stream(R.dev))
+                                  sky_avg.data_ptr(), st["ticket"].data_ptr() if dynamic else None, _stream(R.dev))
     capi.check(rc, "sdn_field_mlp")
 
 
-def mlp_from(R, buf, sky_c, sky_avg, n_rays, ns, window=None, worklist=True):
+def mlp_from(R, buf, sky_c, sky_avg, n_rays, ns, window=None):
     """Second half of field_fused for an already encoded ray set (the pipelined trajectory path)."""
     st = R._fused_style or prepare_style(R)
     net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
-    _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, window=window, worklist=worklist)
+    _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, window=window)
     return net_out
 
 

@@ -230,8 +230,8 @@ def test_sky_mean_finished_in_kernel(renderer):
 
 def test_ray_window_equals_sliced_copies(renderer):
     """encode / mlp reading the frame-wide ray arrays through a window (cropped apron, chunk offsets) produce the bits
-    the same kernels produce on strided-slice COPIES of those rays; the work list (hit groups dealt round-robin)
-    produces the bits of the static group loop."""
+    the same kernels produce on strided-slice COPIES of those rays; the dynamic group schedule (ticket counter)
+    produces the bits of the static one."""
     from scenedreamer_amd import fused
     renderer.set_style_code(golden("field_a.npz")["z"])
     pose, vid, d2, rd, H0, W0 = _frame(renderer)
@@ -245,7 +245,7 @@ def test_ray_window_equals_sliced_copies(renderer):
     cs = sky_c.view(H0, W0, 64)[o:H0 - o, o:W0 - o].reshape(-1, 64).contiguous()
     assert win.n_rays == cv.shape[0]
     ori = torch.as_tensor(pose[0], dtype=torch.float32)
-    b_copy = {k: v.clone() for k, v in fused.encode(renderer, cv, cd, cr, ori, ns).items() if k != "worklist"}
+    b_copy = {k: v.clone() for k, v in fused.encode(renderer, cv, cd, cr, ori, ns).items()}
     b_win = fused.encode(renderer, vid, d2, rd, ori, ns, window=win)
     hit_rows = (cv[:, 0] != 0).view(-1, 1)
     for k in ("dist", "label", "rayflag"):
@@ -254,20 +254,15 @@ def test_ray_window_equals_sliced_copies(renderer):
     tiles = torch.nn.functional.pad(hit_rows.view(-1), (0, (-hit_rows.numel()) % 8)).view(-1, 8).any(dim=1)
     fa, fb = b_copy["feat"].view(tiles.numel(), -1)[tiles], b_win["feat"].view(tiles.numel(), -1)[tiles]
     assert torch.equal(fa, fb)
-    # work list: every group exactly once, hit groups in front
-    wl = b_win["worklist"].cpu().numpy()
-    n_groups = wl.size - 2
-    g_hit = torch.nn.functional.pad(hit_rows.view(-1), (0, (-hit_rows.numel()) % 32)).view(-1, 32).any(dim=1).cpu().numpy()
-    assert wl[0] == g_hit.sum() and wl[0] + wl[1] == n_groups
-    assert sorted(wl[2:2 + wl[0]]) == list(np.nonzero(g_hit)[0]) and sorted(wl[2 + wl[0]:]) == list(np.nonzero(~g_hit)[0])
     st = renderer._fused_style or fused.prepare_style(renderer)
     outs = {}
-    for tag, (buf, sc, w, use_wl) in {"copy": (b_win, cs, None, False), "window": (b_win, sky_c, win, False),
-                                      "worklist": (b_win, sky_c, win, True)}.items():
+    for tag, (buf, sc, w, dyn) in {"copy": (b_win, cs, None, False), "window": (b_win, sky_c, win, False),
+                                   "dynamic": (b_win, sky_c, win, True), "dynamic2": (b_win, sky_c, win, True)}.items():
         no = torch.full((win.n_rays, 64), float("nan"), device="cuda")
-        fused._launch_mlp(renderer, buf, st, sc, sky_avg.reshape(-1), no, win.n_rays, ns, window=w, worklist=use_wl)
+        fused._launch_mlp(renderer, buf, st, sc, sky_avg.reshape(-1), no, win.n_rays, ns, window=w, dynamic=dyn)
         outs[tag] = no
-    assert torch.equal(outs["copy"], outs["window"]) and torch.equal(outs["copy"], outs["worklist"])
+    assert torch.equal(outs["copy"], outs["window"]) and torch.equal(outs["copy"], outs["dynamic"])
+    assert torch.equal(outs["copy"], outs["dynamic2"]) and int(st["ticket"].abs().sum()) == 0     # the counter resets itself
     assert torch.isfinite(outs["copy"]).all()
     # chunked evaluation (ray0 offsets into the window) == one launch
     whole = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win)

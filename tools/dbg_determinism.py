@@ -32,15 +32,13 @@ def main():
         outs = []
         for use_wl in (False, True, True, False):
             no = torch.full((win.n_rays, 64), float("nan"), device="cuda")
-            fused._launch_mlp(R, buf, st, s1, a1.reshape(-1), no, win.n_rays, ns, window=win, worklist=use_wl)
+            fused._launch_mlp(R, buf, st, s1, a1.reshape(-1), no, win.n_rays, ns, window=win, dynamic=use_wl)
             outs.append(no)
         for k in range(1, 4):
             d = (outs[0] - outs[k]).abs()
             bad = (d > 0).any(dim=1).nonzero().reshape(-1)
             print(pi, "mlp", k, "equal", torch.equal(outs[0], outs[k]), "max", d.max().item(), "rays differing", bad.numel(),
                   bad[:8].tolist(), "groups", sorted(set((bad // 32).tolist()))[:8])
-        wl = buf["worklist"].cpu()
-        print(pi, "worklist hit", int(wl[0]), "dead", int(wl[1]), "groups", wl.numel() - 2)
         f1 = R.render_frame(pose, hw, ns, mode="fused")
         f2 = R.render_frame(pose, hw, ns, mode="fused")
         print(pi, "frame twice equal", torch.equal(f1, f2), (f1 - f2).abs().max().item())
