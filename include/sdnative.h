@@ -170,6 +170,10 @@ int sdn_field_collapse_table(const float *embeddings, const int32_t *offsets_hos
  * wc dev [64,256] fc_out_c.weight; packed dev, sdn_field_packed_weight_bytes() bytes */
 int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const float *wc, void *packed,
                            sdn_stream_t stream);
+/* The same stream (same size) with the colour layers fc_5 / fc_6 laid out for colour_terms = 6 of sdn_field_mlp: f16 Whi
+ * fragments + block-scaled fp6 (e2m3) fragments of Wlo and Whi with one E8M0 scale per row and 32-k block. */
+int sdn_field_pack_weights_mx(const float *w1, const float *const *wh5_host, const float *wc, void *packed,
+                              sdn_stream_t stream);
 /* voxel_id dev i32 [R,M]; depth2 dev f32 [2,R,M]; raydirs dev f32 [R,3]; lut1024 dev u8 [1024] block id ->
  * reduced label (ignore already mapped to dirt); scales_dev f32 [16]; outputs: feat, dist, label (aux_elems each),
  * rayflag u8 [R].  Sample placement = mc_utils.sample_depth_batched(nsamples = num_samples + 1, use_box_boundaries =
@@ -193,7 +197,9 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
 int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_dev, int32_t n_rays, int32_t max_blocks,
                      int32_t n_points, float sample_depth, float *rand_depth, float *new_dists, int64_t *idx, sdn_stream_t stream);
 /* sky_c dev f32 [R,64] = sky_net output per ray; net_out dev f32 [R,64]; n_workgroups <= 0 -> one per CU.
- * colour_terms: f16 split terms of the colour layers fc_5 / fc_6: 3 (like every other layer) or 2 (without Whi.Xlo).
+ * colour_terms: products of the colour layers fc_5 / fc_6 (LightningMLP.forward, layers.py:117-124): 3 = the 3-term f16 split
+ *   like every other layer; 2 = without Whi.Xlo; 6 = Whi.Xhi in f16 + the two correction terms as block-scaled fp6
+ *   products at 4x the f16 MFMA rate (`packed` must then come from sdn_field_pack_weights_mx).
  * term_eps: early ray termination -- a 32-ray group stops sampling once the transmittance of all its rays is below
  *   term_eps (changes net_out by at most 2 * term_eps); 0 = off (the reference evaluates every sample).
  * passes: optional dev u8 [ceil(ceil(R / 8) / 4)], number of 4-sample passes every 32-ray group went through.

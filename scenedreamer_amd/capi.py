@@ -51,6 +51,7 @@ _SIGNATURES = {
     "sdn_field_aux_elems": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "sdn_field_collapse_table": (c_i, [c_p, c_p, c_u, c_f, c_u, c_p, c_p, c_p]),
     "sdn_field_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    "sdn_field_pack_weights_mx": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_field_encode": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sdn_sample_depth": (c_i, [c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p]),

@@ -45,6 +45,7 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int HID = 256;        // hidden width (layers.py:62)
 constexpr int FEAT = 128;       // hash-grid output width: 16 levels x 8 channels
@@ -230,6 +231,70 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
     }
     p.out[base + ((size_t)u * 4 + 2 * sel + 0) * 64 + lane] = hi;
     p.out[base + ((size_t)u * 4 + 2 * sel + 1) * 64 + lane] = lo;
+}
+
+// ---- MX variant of the packed stream: fc_5 / fc_6 (packed layers 4 and 5) in the layout of layer8x ---------------------
+// fp6 e2m3 code of |v| <= 7.5 (round to nearest even; the 32 non-negative codes are contiguous in value order)
+__device__ inline unsigned fp6_code(float v) {
+    const float a = fminf(fabsf(v), 7.5f);
+    float c;
+    if (a < 2.f) c = rintf(a * 8.f);                 // 0 .. 16: subnormals and the binade [1, 2), step 1/8
+    else if (a < 4.f) c = 16.f + rintf((a - 2.f) * 4.f);
+    else c = 24.f + rintf((a - 4.f) * 2.f);
+    const unsigned code = (unsigned)fminf(c, 31.f);
+    return code | (v < 0.f ? 32u : 0u);
+}
+
+struct PackMxParams {
+    const float *wh[2];   // fc_5, fc_6 weights with alpha folded, [256,256]
+    half8 *out;           // the packed stream (all layers already written by pack_kernel)
+};
+
+__global__ __launch_bounds__(256) void pack_mx_kernel(const PackMxParams p) {
+#pragma clang fp contract(off)   // hi = f16(f32(W * 0.4)) in both branches: a fused multiply would break exact ties differently
+    const int g = blockIdx.x * 256 + threadIdx.x;    // one thread per (layer, unit, lane)
+    if (g >= 2 * 64 * 64) return;
+    const int lane = g % 64, u = (g / 64) % 64, layer = g / (64 * 64);
+    const float *W = p.wh[layer];
+    half8 *out = p.out + L0_FRAGS + (size_t)(3 + layer) * LH_FRAGS + (size_t)u * 4 * 64;
+    const int half = u / 32, kb = (u % 32) / 8, sub = u % 8, ib0 = 4 * half, h = lane >> 5;
+    if (sub < 4) {   // f16 hi fragments of k-step 4 kb + sub for the half's 4 row blocks
+        const int s = 4 * kb + sub;
+        for (int f = 0; f < 4; f++) {
+            const int row = 32 * (ib0 + f) + (lane & 31);
+            half8 hi;
+            for (int e = 0; e < 8; e++) hi[e] = (_Float16)(W[(size_t)row * HID + kmap_hidden(s, h, e)] * ACT_SCALE);
+            out[f * 64 + lane] = hi;
+        }
+        return;
+    }
+    const int term = (sub - 4) / 2, iba = ib0 + 2 * ((sub - 4) % 2);   // term 0: Wlo (x x6), term 1: Whi (x xl6)
+    for (int rb = 0; rb < 2; rb++) {
+        const int row = 32 * (iba + rb) + (lane & 31);
+        float v[32], vmax = 0.f;
+        for (int i = 0; i < 32; i++) {
+            const float w = W[(size_t)row * HID + kmap_hidden(4 * kb + i / 8, h, i % 8)] * ACT_SCALE;
+            const float hi = (float)(_Float16)w;
+            v[i] = term == 0 ? w - hi : hi;
+            vmax = fmaxf(vmax, fabsf(v[i]));
+        }
+        int e = 0;   // smallest power of two with vmax <= 7.5 * 2^e
+        if (vmax > 0.f) {
+            e = (int)floorf(log2f(vmax / 7.5f)) - 1;
+            while (ldexpf(7.5f, e) < vmax) e++;
+        }
+        if (e < -126) e = -126;
+        unsigned w6[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+        for (int i = 0; i < 32; i++) {
+            const unsigned long long code = fp6_code(ldexpf(v[i], -e));
+            const int bit = 6 * i, d = bit >> 5, o = bit & 31;
+            w6[d] |= (unsigned)(code << o);
+            if (o > 26) w6[d + 1] |= (unsigned)(code >> (32 - o));
+        }
+        u32x4v f0 = {w6[0], w6[1], w6[2], w6[3]}, f1 = {w6[4], w6[5], (unsigned)(127 + e), 0u};
+        out[(2 * rb) * 64 + lane] = __builtin_bit_cast(half8, f0);
+        out[(2 * rb + 1) * 64 + lane] = __builtin_bit_cast(half8, f1);
+    }
 }
 
 // =====================================================================================================
@@ -722,8 +787,6 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
     return r;
 }
 
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-
 // write two packed f16 pairs into dwords 2*HS, 2*HS+1 of a fragment (whole-dword moves: 16-bit element inserts
 // into a half8 are lowered through scratch memory by hipcc)
 template <int HS>
@@ -943,6 +1006,192 @@ __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half
                                                                              bl, acc, bias, bias_pend, wsig, h, part);
 }
 
+// =====================================================================================================
+// Colour layers as  Whi.Xhi (f16)  +  block-scaled fp6 corrections  [Wlo | Whi] . [X ; Xlo]
+// =====================================================================================================
+// The two correction terms of the 3-term split only need ~5 significant bits (their sum is 2^-11 of the product), so in
+// the layers whose error nothing amplifies (fc_5, fc_6: the colour branch) they are evaluated with
+// v_mfma_scale_f32_32x32x64_f8f6f4 on fp6 (e2m3) operands: K = 64 per instruction at the issue cost of one K = 16 f16
+// MFMA.  192 MFMAs per layer instead of 384; measured error of the emulation (tools/precision_study.py) 4e-5 on net_out
+// against 5-7e-4 for simply dropping a term.  Operand facts (pinned on the hardware by tools/mx_probe.hip): lane l holds
+// row / column l & 31 and the 32 k values 32 * (l >> 5) + i as 6-bit fields, little endian, in 6 dwords; the E8M0 scale
+// byte (2^(b - 127)) of the lane's 32-value block comes from byte OPSEL of a per-lane VGPR;
+// v_cvt_scalef32_pk32_fp6_f16 converts 32 f16 (16 VGPRs, element p -> field p) dividing by a power-of-two scale, round to
+// nearest even, saturating at 7.5.
+//   B operands: K block kb = features 64 kb .. 64 kb + 63 = B fragments 4 kb .. 4 kb + 3; a lane's 32 values are its 8
+//   elements of each of the 4 fragments (the cvt instruction reads the 16 VGPRs of bh[4kb .. 4kb+3] / bl[...] as they are).
+//   Per-lane scale: biased exponent of the block's max |x| minus 2 (max lands in [4, 8): at most the top value saturates),
+//   the lo block uses that exponent minus 11 (|x - f16(x)| <= 2^-11 of x's binade).
+//   A operands: packed by pack_mx_kernel with one scale per row and 32-k block.
+typedef unsigned int u32x6v __attribute__((ext_vector_type(6)));
+typedef int i32x8v __attribute__((ext_vector_type(8)));
+typedef _Float16 half32 __attribute__((ext_vector_type(32)));
+
+struct MxState {
+    u32x6v x6[4], xl6[4];   // fp6 images of the hi / lo f16 fragments of K block kb
+    int sx[4];              // byte 0: scale of x6[kb], byte 1: scale of xl6[kb]
+    float bm[4];            // running max |x| of K block kb (reset by mx_convert)
+};
+// (Keeping the fp6 images in the registers of the lo fragments they replace -- bl[4kb .. 4kb+3] are dead once converted --
+// was tried: hipcc then fuses the reads of neighbouring fragments into 32-byte loads of the fragment array, which sends
+// the array to scratch memory; with that blocked, the contiguity constraints cost more moves and spills than the 52
+// extra registers of this struct.)
+
+__device__ __forceinline__ half32 cat4(const half8 &a, const half8 &b, const half8 &c, const half8 &d) {
+    const auto ab = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    const auto cd = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    return __builtin_shufflevector(ab, cd, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25,
+                                   26, 27, 28, 29, 30, 31);
+}
+
+template <int KB>
+__device__ __forceinline__ void mx_convert(const half8 (&bh)[16], const half8 (&bl)[16], MxState &mx) {
+    int e = (int)((__builtin_bit_cast(unsigned int, mx.bm[KB]) >> 23) & 255u) - 2;
+    e = e < 12 ? 12 : e;                                   // e - 11 stays a normal scale; such blocks are ~0 anyway
+    const float s_hi = __builtin_bit_cast(float, (unsigned int)e << 23);
+    const float s_lo = __builtin_bit_cast(float, (unsigned int)(e - 11) << 23);
+    mx.x6[KB] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(cat4(bh[4 * KB], bh[4 * KB + 1], bh[4 * KB + 2], bh[4 * KB + 3]), s_hi);
+    mx.xl6[KB] = __builtin_amdgcn_cvt_scalef32_pk32_fp6_f16(cat4(bl[4 * KB], bl[4 * KB + 1], bl[4 * KB + 2], bl[4 * KB + 3]), s_lo);
+    mx.sx[KB] = e | ((e - 11) << 8);
+    mx.bm[KB] = 0.f;
+}
+
+// one fp6 MFMA: A = the two 16-byte ring fragments of an fp6 weight fragment (6 dwords of fields, scale word, pad),
+// B = a fp6 activation block, OPB = which byte of sb is its scale
+template <int OPB>
+__device__ __forceinline__ f32x16 mfma_mx(const half8 &a_lo, const half8 &a_hi, const u32x6v &b, f32x16 c, int sb) {
+    // every dword of a ring fragment must stay allocated until its (asynchronous, hand-waited) ds_read has landed: the
+    // pad dword of a_hi is not an MFMA operand, so it is named here -- otherwise hipcc reuses that register as a
+    // temporary right behind the read's issue and the data landing later overwrites it (found the hard way:
+    // tools/check_lds_hazards.py reports exactly this)
+    asm volatile("" ::"v"(a_hi));
+    const u32x4v w0 = __builtin_bit_cast(u32x4v, a_lo), w1 = __builtin_bit_cast(u32x4v, a_hi);
+    const i32x8v A = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], 0, 0};
+    const i32x8v B = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], (int)b[4], (int)b[5], 0, 0};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 2, 2, 0, (int)w1[2], OPB, sb);
+}
+
+// act_stage + running block max (the f32 activations of stage 2 are at hand in stage 3)
+template <int T, int HS, bool SIG, int STAGE, bool MXT>
+__device__ __forceinline__ void act_stage_x(const f32x16 (&acc)[8], const ActIn &in, half8 (&bh)[16], half8 (&bl)[16], MxState &mx,
+                                            float &part, ActRegs &g) {
+    act_stage<T, HS, SIG, STAGE, true>(acc, in, bh, bl, part, g);
+    if constexpr (MXT && STAGE == 3) {
+        float m = mx.bm[T / 4];
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(g.x[0]), "v"(g.x[1]));
+        asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(g.x[2]), "v"(g.x[3]));
+        mx.bm[T / 4] = m;
+    }
+}
+
+// KIND 0: an ordinary 3-term layer whose OUTPUT feeds an MX layer (fc_4): its upper half is activated into f16 hi/lo
+//         fragments 0..7 as always, K block 0 is converted at unit 56, K block 1 by the consumer's unit 0.
+// KIND 1: MX layer fed by and feeding MX (fc_5).   KIND 2: MX layer whose output feeds a 3-term layer (fc_6 -> fc_out_c).
+// MX unit order (pack_mx_kernel): per output half (row blocks 4*half .. +3) and K block kb, 8 units of 4 KiB:
+//   0..3  f16 fragments of k-step 4 kb + t for the half's 4 row blocks                         -> 4 MFMAs
+//   4, 5  fp6 Wlo fragments of row blocks (0,1) / (2,3) of the half  x  x6[kb]                  -> 2 MFMAs each
+//   6, 7  fp6 Whi fragments of row blocks (0,1) / (2,3)              x  xl6[kb]                 -> 2 MFMAs each
+// The activation schedule (which half fragment is activated behind which unit) is layer8's.
+template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN, int U>
+__device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16], MxState &mx,
+                                             f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
+                                             int h, float &part) {
+    constexpr int NS = 16, UNITS = 64, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
+    constexpr bool MXL = KIND != 0;
+    using P = ActPlan<DBG, NS, true, SIG_PEND, SIG_OWN, U>;
+    if constexpr (U % UPS == 0 && U != 0) {
+        st.pos_cur = ring_acquire<DBG>(lds, r);
+        st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    }
+    constexpr int UN = U + RD - 1;
+    constexpr bool PF = UN < UNITS;
+    const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
+    constexpr int T = P::T, HS = P::HS;
+    constexpr bool SIG = P::SIG, ACT = P::ACT;
+    // does the fragment activated here feed an MX layer?  PEND fragments (8..15) feed THIS layer, OWN fragments the next
+    constexpr bool MXT = P::PEND ? MXL : KIND != 2;
+    // K blocks completed by the previous unit: converted in this unit's first gap
+    constexpr int CONV = (MXL && U == 0) ? 1 : (MXL && U == 8) ? 2 : (MXL && U == 16) ? 3 : (KIND != 2 && U == 56) ? 0 : -1;
+    ActRegs g;
+    half8(&a)[4] = st.ring[U % RD];
+    half8(&nx)[4] = st.ring[UN % RD];
+    const ActIn &in = st.in[U & 1];
+    constexpr bool PF_PREV = U == 0 || (U - 1 + RD - 1) < UNITS;
+    lds_wait<PF_PREV ? 4 : 0>();
+    layer8_fetch<DBG, NS, true, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
+#define SDN_STAGE(K) \
+    if constexpr (U % UPS < PIECES / 4 && K < 4) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
+    if constexpr (CONV >= 0 && K == 0) mx_convert<CONV < 0 ? 0 : CONV>(bh, bl, mx); \
+    if constexpr (ACT) act_stage_x<T, HS, SIG, K, MXT>(acc, in, bh, bl, mx, part, g); \
+    if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!MXL) {
+        constexpr int S = P::S, IB = 4 * P::HALF + 2 * (P::REM & 1);
+        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], zero16());
+        else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
+        SDN_STAGE(0)
+        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], zero16());
+        else acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
+        SDN_STAGE(1)
+        acc[IB] = mfma16(a[1], bh[S], acc[IB]);
+        SDN_STAGE(2)
+        acc[IB + 1] = mfma16(a[3], bh[S], acc[IB + 1]);
+        SDN_STAGE(3)
+        acc[IB] = mfma16(a[0], bl[S], acc[IB]);
+        SDN_STAGE(4)
+        acc[IB + 1] = mfma16(a[2], bl[S], acc[IB + 1]);
+        SDN_STAGE(5)
+    } else {
+        constexpr int HALF = U / 32, KB = (U % 32) / 8, SUB = U % 8, IB0 = 4 * HALF;
+        if constexpr (SUB < 4) {
+            constexpr int S = 4 * KB + SUB;
+            if constexpr (S == 0) acc[IB0] = mfma16(a[0], bh[S], zero16());
+            else acc[IB0] = mfma16(a[0], bh[S], acc[IB0]);
+            SDN_STAGE(0) SDN_STAGE(1)
+            if constexpr (S == 0) acc[IB0 + 1] = mfma16(a[1], bh[S], zero16());
+            else acc[IB0 + 1] = mfma16(a[1], bh[S], acc[IB0 + 1]);
+            SDN_STAGE(2)
+            if constexpr (S == 0) acc[IB0 + 2] = mfma16(a[2], bh[S], zero16());
+            else acc[IB0 + 2] = mfma16(a[2], bh[S], acc[IB0 + 2]);
+            SDN_STAGE(3)
+            if constexpr (S == 0) acc[IB0 + 3] = mfma16(a[3], bh[S], zero16());
+            else acc[IB0 + 3] = mfma16(a[3], bh[S], acc[IB0 + 3]);
+            SDN_STAGE(4) SDN_STAGE(5)
+        } else {
+            constexpr int TERM = (SUB - 4) / 2, IBA = IB0 + 2 * ((SUB - 4) % 2);
+            constexpr bool ON = !(DBG & (TERM == 0 ? 32 : 64));   // ablation: DBG & 32 drops Wlo.X, DBG & 64 drops Whi.Xlo
+            if constexpr (!ON) asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]));
+            if constexpr (ON && TERM == 0) acc[IBA] = mfma_mx<0>(a[0], a[1], mx.x6[KB], acc[IBA], mx.sx[KB]);
+            if constexpr (ON && TERM == 1) acc[IBA] = mfma_mx<1>(a[0], a[1], mx.xl6[KB], acc[IBA], mx.sx[KB]);
+            SDN_STAGE(0) SDN_STAGE(1) SDN_STAGE(2)
+            if constexpr (ON && TERM == 0) acc[IBA + 1] = mfma_mx<0>(a[2], a[3], mx.x6[KB], acc[IBA + 1], mx.sx[KB]);
+            if constexpr (ON && TERM == 1) acc[IBA + 1] = mfma_mx<1>(a[2], a[3], mx.xl6[KB], acc[IBA + 1], mx.sx[KB]);
+            SDN_STAGE(3) SDN_STAGE(4) SDN_STAGE(5)
+        }
+    }
+#undef SDN_STAGE
+}
+
+template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN, int... Us>
+__device__ __forceinline__ void layer8x_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st, half8 (&bh)[16],
+                                              half8 (&bl)[16], MxState &mx, f32x16 (&acc)[8], const float *bias,
+                                              const float *bias_pend, const float *wsig, int h, float &part) {
+    (layer8x_unit<DBG, KIND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, mx, acc, bias, bias_pend, wsig, h, part), ...);
+}
+
+template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN>
+__device__ __forceinline__ void layer8x(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], MxState &mx, f32x16 (&acc)[8],
+                                        const float *bias, const float *bias_pend, const float *wsig, int h, float &part) {
+    LayerState st;
+    st.pos_cur = ring_acquire<DBG>(lds, r);
+    st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    layer8_fetch<DBG, 16, true, SIG_PEND, SIG_OWN, 0>(bias, bias_pend, wsig, h, st);
+    lds_unit<0>(r, st.pos_cur, st.ring[0]);
+    lds_unit<1>(r, st.pos_cur, st.ring[1]);
+    layer8x_units<DBG, KIND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, 64>{}, lds, r, st, bh, bl, mx, acc, bias, bias_pend,
+                                                wsig, h, part);
+}
+
 // Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of the last hidden layer is
 // activated behind its first 8 k-steps (one whole fragment = two half fragments per unit).
 struct OutState {
@@ -1100,6 +1349,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             const size_t tc = (size_t)(tile_ok ? tile : 0) * p.nch + ch;
             half8 bh[16], bl[16];
             f32x16 acc[8];
+            MxState mx;
+            if constexpr (CT == 6) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) mx.bm[k] = 0.f;
+            }
             const float *fin = p.feat + (tc * 8 * 64 + lane) * 8;
             unsigned long long t_in0 = 0;
             if constexpr (DBG & 128) t_in0 = __builtin_readcyclecounter();
@@ -1170,14 +1424,21 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             // ---- fc_2 .. fc_6.  fc_4 (l == 2) feeds the density head (layers.py:114): its upper half is activated
             //      inside l == 2, its lower half as the pending work of l == 3 ----------------------------------------
 #pragma unroll 1
-            for (int l = 0; l < 5; l++) {
+            for (int l = 0; l < 5; l++) {   // (straight-line code instead of this loop: 1.5 KB of scratch spills -- tried)
                 const float *bias = cst + C_BETA + l * HID;
                 const float *bias_pend = l == 0 ? bias1 : bias - HID;   // the previous layer's (its lower half is pending)
-                // fc_4's upper half feeds fc_5, fc_5's activations feed fc_5 / fc_6: no lo parts when those are 2-term
-                if (l == 2) layer8<DBG, 16, true, false, true, 3, true, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
-                else if (l == 3) layer8<DBG, 16, true, true, false, CT, CT == 3, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
-                else if (CT != 3 && l == 4) layer8<DBG, 16, true, false, false, CT, CT == 3, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
-                else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                if constexpr (CT == 6) {   // colour layers: f16 Whi.Xhi + fp6 corrections (layer8x)
+                    if (l == 2) layer8x<DBG, 0, false, true>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
+                    else if (l == 3) layer8x<DBG, 1, true, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
+                    else if (l == 4) layer8x<DBG, 2, false, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
+                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                } else {
+                    // fc_4's upper half feeds fc_5, fc_5's activations feed fc_5 / fc_6: no lo parts when those are 2-term
+                    if (l == 2) layer8<DBG, 16, true, false, true, 3, true, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                    else if (l == 3) layer8<DBG, 16, true, true, false, CT, CT == 3, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                    else if (CT != 3 && l == 4) layer8<DBG, 16, true, false, false, CT, CT == 3, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                }
             }
             // ---- fc_out_c ------------------------------------------------------------------------------------------
             {   // inputs of the next pass of this wave: the next step of this tile, or the first step of its next group
@@ -1596,6 +1857,16 @@ int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const 
     return sdn::check_launch("sdn_field_pack_weights");
 }
 
+int sdn_field_pack_weights_mx(const float *w1, const float *const *wh5_host, const float *wc, void *packed, sdn_stream_t stream) {
+    if (int rc = sdn_field_pack_weights(w1, wh5_host, wc, packed, stream)) return rc;
+    PackMxParams p;
+    p.wh[0] = wh5_host[3];   // fc_5
+    p.wh[1] = wh5_host[4];   // fc_6
+    p.out = (half8 *)packed;
+    hipLaunchKernelGGL(pack_mx_kernel, dim3(2 * 64 * 64 / 256), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_field_pack_weights_mx");
+}
+
 size_t sdn_field_feat_bytes(int32_t n_rays, int32_t num_samples) {
     const size_t tiles = (size_t)sdn::div_up(n_rays, RAYS_PER_TILE), nch = (size_t)sdn::div_up(num_samples, SAMP_PER_STEP);
     return tiles * nch * 8 * 64 * 8 * sizeof(float);
@@ -1672,7 +1943,7 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
                   const float *sky_avg, int32_t *ticket, sdn_stream_t stream) {
     SDN_REQUIRE(feat && dist && label && rayflag && packed && consts && sky_c && net_out, "sdn_field_mlp: null pointer");
     SDN_REQUIRE(n_rays > 0 && num_samples > 0, "sdn_field_mlp: empty frame");
-    SDN_REQUIRE(colour_terms == 2 || colour_terms == 3, "sdn_field_mlp: colour_terms must be 2 or 3");
+    SDN_REQUIRE(colour_terms == 2 || colour_terms == 3 || colour_terms == 6, "sdn_field_mlp: colour_terms must be 2, 3 or 6");
     SDN_REQUIRE(term_eps >= 0.f && term_eps < 1.f, "sdn_field_mlp: term_eps must be in [0, 1)");
     MlpParams p;
     p.term_depth = term_eps > 0.f ? -logf(term_eps) : 0.f;
@@ -1703,9 +1974,13 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
         case 8: hipLaunchKernelGGL((mlp_kernel<8, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;   // no fragment ds_read
         case 16: hipLaunchKernelGGL((mlp_kernel<16, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // no MFMA
         case 28: hipLaunchKernelGGL((mlp_kernel<28, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+        case 32: hipLaunchKernelGGL((mlp_kernel<32, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;  // colour layers without Wlo.X
+        case 64: hipLaunchKernelGGL((mlp_kernel<64, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;  // ... without Whi.Xlo
+        case 96: hipLaunchKernelGGL((mlp_kernel<96, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;  // ... Whi.Xhi only
 #endif
         default:
             if (colour_terms == 2) hipLaunchKernelGGL((mlp_kernel<0, 2>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+            else if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
             else hipLaunchKernelGGL((mlp_kernel<0, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
             break;
     }

@@ -69,17 +69,21 @@ def prepare_scene(R):
 
 
 def prepare_style(R):
-    """Pack the folded MLP weights into MFMA fragment order + build the fp32 constant block (once per style)."""
+    """Pack the folded MLP weights into MFMA fragment order + build the fp32 constant block (once per style).  Two images
+    of the stream: the 3-term f16 split everywhere, and the one with the colour layers as f16 + fp6 (colour_terms = 6)."""
     lib = _lib()
     w = R.w
     packed = torch.empty(lib.sdn_field_packed_weight_bytes(), dtype=torch.uint8, device=R.dev)
+    packed_mx = torch.empty_like(packed)
     wh = [R.mod[i][0].contiguous() for i in (2, 3, 4, 5, 6)]
     ptrs = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in wh])
     w1 = w["render_net.fc_1.weight"].contiguous()
     wc = w["render_net.fc_out_c.weight"].contiguous()
     with torch.cuda.device(R.dev):
         rc = lib.sdn_field_pack_weights(w1.data_ptr(), ptrs, wc.data_ptr(), packed.data_ptr(), _stream(R.dev))
-    capi.check(rc, "sdn_field_pack_weights")
+        capi.check(rc, "sdn_field_pack_weights")
+        rc = lib.sdn_field_pack_weights_mx(w1.data_ptr(), ptrs, wc.data_ptr(), packed_mx.data_ptr(), _stream(R.dev))
+    capi.check(rc, "sdn_field_pack_weights_mx")
     consts = torch.zeros(lib.sdn_field_consts_floats(), dtype=torch.float32, device=R.dev)
     off = [lib.sdn_field_const_offset(i) for i in range(6)]
     consts[off[0]:off[0] + 12 * 256] = R.label_bias.reshape(-1)
@@ -88,7 +92,7 @@ def prepare_style(R):
     consts[off[2]:off[2] + 256] = w["render_net.fc_sigma.weight"].reshape(-1) * 0.4
     consts[off[3]:off[3] + 64] = w["render_net.fc_out_c.bias"]
     consts[off[4]] = w["render_net.fc_sigma.bias"].reshape(-1)[0]
-    R._fused_style = dict(packed=packed, consts=consts, sky_off=off[5], keep=wh)
+    R._fused_style = dict(packed=packed, packed_mx=packed_mx, consts=consts, sky_off=off[5], keep=wh)
     return R._fused_style
 
 
@@ -172,8 +176,8 @@ def _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, passes=None, wi
         st["ticket"] = torch.zeros(2, dtype=torch.int32, device=R.dev)      # the kernel leaves it at zero
     with torch.cuda.device(R.dev):
         rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                  buf["rayflag"].data_ptr(), st["packed"].data_ptr(), st["consts"].data_ptr(),
-                                  sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, ct, eps,
+                                  buf["rayflag"].data_ptr(), st["packed_mx" if ct == 6 else "packed"].data_ptr(),
+                                  st["consts"].data_ptr(), sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, ct, eps,
                                   passes.data_ptr() if passes is not None else None, 0, window.host(ray0),
                                   sky_avg.data_ptr(), st["ticket"].data_ptr() if dynamic else None, _stream(R.dev))
     capi.check(rc, "sdn_field_mlp")

@@ -164,7 +164,7 @@ def test_colour_layers_two_term_within_budget(renderer, tag):
     renderer.global_enc = torch.from_numpy(g["global_enc"]).cuda()
     errs = {}
     try:
-        for ct in (3, 2):
+        for ct in (3, 2, 6):
             renderer.colour_terms = ct
             with torch.no_grad():
                 sky_c = renderer.sky_features(rd)
@@ -176,8 +176,10 @@ def test_colour_layers_two_term_within_budget(renderer, tag):
     finally:
         renderer.colour_terms = None
     print(f"golden {tag}: net_out / image max abs err  3-term {errs[3][0]:.2e} / {errs[3][1]:.2e}   "
-          f"colour 2-term {errs[2][0]:.2e} / {errs[2][1]:.2e}")
+          f"colour 2-term {errs[2][0]:.2e} / {errs[2][1]:.2e}   colour f16+fp6 {errs[6][0]:.2e} / {errs[6][1]:.2e}")
     assert errs[2][0] < TOL and errs[2][1] < TOL
+    # f16 Whi.Xhi + block-scaled fp6 corrections: within 1e-4 of the 3-term kernel's error (emulation: 4e-5)
+    assert errs[6][0] < errs[3][0] + 1e-4 and errs[6][1] < errs[3][1] + 1e-4
 
 
 def test_early_ray_termination(weights_full, scene256):

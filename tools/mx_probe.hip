@@ -87,6 +87,22 @@ int main() {
         for (int p = 0; p < 32; p++) printf(" [%d]=%g", p, dec6(c[p]));
         printf("\n");
     }
+    // small inputs with a small scale: the lo block of the field MLP (|x - f16(x)| <= 2^-11 |x|, scale 2^(e - 13))
+    for (int k = 9; k <= 15; k += 2) {
+        float t[32];
+        const float sc = std::ldexp(1.f, -k);
+        for (int i = 0; i < 32; i++) t[i] = dec6(i) * sc * ((i & 1) ? -1.f : 1.f);
+        CK(hipMemcpy(d_in, t, sizeof(t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(cvt_kernel, dim3(1), dim3(1), 0, 0, d_in, d_out, sc);
+        unsigned h_out[12];
+        CK(hipMemcpy(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost));
+        int c[32], bad16 = 0, bad32 = 0;
+        decode(h_out + 6, c);
+        for (int p = 0; p < 32; p++) bad16 += c[p] != (p | ((p & 1) && p ? 32 : 0));
+        decode(h_out, c);
+        for (int p = 0; p < 32; p++) { const int i = (p & 1) ? 16 + p / 2 : p / 2; bad32 += c[p] != (i | ((i & 1) && i ? 32 : 0)); }
+        printf("scale 2^-%d, inputs dec6(i) * 2^-%d (f16 inputs become subnormal below 2^-14): wrong codes pk32_fp6_f16 %d, 2xpk16_fp6_f32 %d\n", k, k, bad16, bad32);
+    }
     // ---- 2. MFMA ----------------------------------------------------------------------------------------------------
     std::vector<int> Ac(32 * 64), Bc(64 * 32);
     srand(1);
@@ -111,21 +127,24 @@ int main() {
     CK(hipMalloc(&dA, 64 * 8 * 4)); CK(hipMalloc(&dB, 64 * 8 * 4)); CK(hipMalloc(&dC, 64 * 16 * 4)); CK(hipMalloc(&dsa, 256)); CK(hipMalloc(&dsb, 256));
     CK(hipMemcpy(dA, Ap.data(), 64 * 8 * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, Bp.data(), 64 * 8 * 4, hipMemcpyHostToDevice));
-    for (int test = 0; test < 4; test++) {
+    for (int test = 0; test < 6; test++) {
         int sa[64], sb[64], ea[64], eb[64];
         for (int l = 0; l < 64; l++) {
             ea[l] = test == 0 ? 0 : (l % 3) - 1;            // exponent of the lane's A block (row l&31, k-half l>>5)
             eb[l] = test == 0 ? 0 : (l >> 5) + ((l & 31) % 2);
             const int ba = 127 + ea[l], bb = 127 + eb[l];
             // tests 0/1: scale in byte 0; test 2: scale in byte 1 (opsel 1), byte 0 = junk; test 3: byte 2 / byte 3
-            sa[l] = test <= 1 ? ba : (test == 2 ? (ba << 8) | 0x11 : (ba << 16) | 0x2211);
-            sb[l] = test <= 1 ? bb : (test == 2 ? (bb << 8) | 0x33 : (bb << 24) | 0x554433);
+            // test 4: A byte 0, B byte 1 (byte 0 = junk); test 5: A byte 1, B byte 0
+            sa[l] = test <= 1 ? ba : (test == 2 ? (ba << 8) | 0x11 : test == 3 ? (ba << 16) | 0x2211 : test == 4 ? ba | 0x6600 : (ba << 8) | 0x11);
+            sb[l] = test <= 1 ? bb : (test == 2 ? (bb << 8) | 0x33 : test == 3 ? (bb << 24) | 0x554433 : test == 4 ? (bb << 8) | 0x33 : bb | 0x7700);
         }
         CK(hipMemcpy(dsa, sa, 256, hipMemcpyHostToDevice));
         CK(hipMemcpy(dsb, sb, 256, hipMemcpyHostToDevice));
         if (test <= 1) hipLaunchKernelGGL((mfma_kernel<0, 0>), dim3(1), dim3(64), 0, 0, dA, dB, dC, dsa, dsb);
         else if (test == 2) hipLaunchKernelGGL((mfma_kernel<1, 1>), dim3(1), dim3(64), 0, 0, dA, dB, dC, dsa, dsb);
-        else hipLaunchKernelGGL((mfma_kernel<2, 3>), dim3(1), dim3(64), 0, 0, dA, dB, dC, dsa, dsb);
+        else if (test == 3) hipLaunchKernelGGL((mfma_kernel<2, 3>), dim3(1), dim3(64), 0, 0, dA, dB, dC, dsa, dsb);
+        else if (test == 4) hipLaunchKernelGGL((mfma_kernel<0, 1>), dim3(1), dim3(64), 0, 0, dA, dB, dC, dsa, dsb);
+        else hipLaunchKernelGGL((mfma_kernel<1, 0>), dim3(1), dim3(64), 0, 0, dA, dB, dC, dsa, dsb);
         float hC[64 * 16];
         CK(hipMemcpy(hC, dC, sizeof(hC), hipMemcpyDeviceToHost));
         double maxerr = 0, maxref = 0;
