@@ -257,8 +257,12 @@ int32_t sdn_sky_partial_rows(int32_t n_rays, int32_t n_workgroups);
 size_t sdn_sky_packed_weight_bytes(void);
 size_t sdn_sky_consts_floats(void);
 int sdn_sky_pack_weights(const float *w1, const float *const *wh4_host, const float *wc, void *packed, sdn_stream_t stream);
+/* the same stream with the hidden layers fc2..fc5 laid out for hidden_terms = 6 (f16 Whi fragments + block-scaled fp6) */
+int sdn_sky_pack_weights_mx(const float *w1, const float *const *wh4_host, const float *wc, void *packed, sdn_stream_t stream);
+/* hidden_terms: products of fc2..fc5: 3 = the 3-term f16 split, 6 = Whi.Xhi in f16 + block-scaled fp6 corrections (packed from
+ * sdn_sky_pack_weights_mx); fc1 and fc_out_c always use the 3-term split */
 int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_partial, int32_t n_rays,
-                int32_t n_workgroups, float *sky_avg, uint32_t *counter, sdn_stream_t stream);
+                int32_t n_workgroups, float *sky_avg, uint32_t *counter, int32_t hidden_terms, sdn_stream_t stream);
 
 /* test hook: C[32,32] = A[32,16] * B[16,32] through the MFMA operand layouts field.hip relies on */
 int sdn_debug_mfma_probe(const float *A, const float *B, float *C, sdn_stream_t stream);

@@ -60,8 +60,9 @@ _SIGNATURES = {
     "sdn_sky_packed_weight_bytes": (ctypes.c_size_t, []),
     "sdn_sky_consts_floats": (ctypes.c_size_t, []),
     "sdn_sky_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    "sdn_sky_pack_weights_mx": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_sky_partial_rows": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
-    "sdn_sky_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p, c_p]),
+    "sdn_sky_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p, ctypes.c_int32, c_p]),
     "sdn_conv_plane_dims": (None, [c_i, c_i, c_p, c_p]),
     "sdn_conv_packed_weight_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "sdn_conv_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),

@@ -246,17 +246,19 @@ __device__ inline unsigned fp6_code(float v) {
 }
 
 struct PackMxParams {
-    const float *wh[2];   // fc_5, fc_6 weights with alpha folded, [256,256]
-    half8 *out;           // the packed stream (all layers already written by pack_kernel)
+    const float *wh[4];   // up to 4 hidden layers' weights [256,256] (field: fc_5, fc_6 with alpha folded; sky: fc2..fc5)
+    int n_layers;
+    size_t base;          // fragment index of the first of those layers in the packed stream
+    half8 *out;           // the packed stream (all layers already written by pack_kernel / sky_pack_kernel)
 };
 
 __global__ __launch_bounds__(256) void pack_mx_kernel(const PackMxParams p) {
 #pragma clang fp contract(off)   // hi = f16(f32(W * 0.4)) in both branches: a fused multiply would break exact ties differently
     const int g = blockIdx.x * 256 + threadIdx.x;    // one thread per (layer, unit, lane)
-    if (g >= 2 * 64 * 64) return;
+    if (g >= p.n_layers * 64 * 64) return;
     const int lane = g % 64, u = (g / 64) % 64, layer = g / (64 * 64);
     const float *W = p.wh[layer];
-    half8 *out = p.out + L0_FRAGS + (size_t)(3 + layer) * LH_FRAGS + (size_t)u * 4 * 64;
+    half8 *out = p.out + p.base + (size_t)layer * LH_FRAGS + (size_t)u * 4 * 64;
     const int half = u / 32, kb = (u % 32) / 8, sub = u % 8, ib0 = 4 * half, h = lane >> 5;
     if (sub < 4) {   // f16 hi fragments of k-step 4 kb + sub for the half's 4 row blocks
         const int s = 4 * kb + sub;
@@ -1071,6 +1073,22 @@ __device__ __forceinline__ f32x16 mfma_mx(const half8 &a_lo, const half8 &a_hi, 
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 2, 2, 0, (int)w1[2], OPB, sb);
 }
 
+// running block max of K block KB taken from the finished f16 hi fragments (used where the activations were not produced by
+// act_stage_x: the sky MLP's first layer).  |x| as 15-bit patterns order like the values; only the exponent is used.
+typedef unsigned short u16x2v __attribute__((ext_vector_type(2)));
+template <int KB>
+__device__ __forceinline__ void mx_block_max_f16(const half8 (&bh)[16], MxState &mx) {
+    u16x2v m = {0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const u32x4v w = __builtin_bit_cast(u32x4v, bh[4 * KB + t]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) m = __builtin_elementwise_max(m, __builtin_bit_cast(u16x2v, w[k] & 0x7fff7fffu));
+    }
+    const unsigned int top = m[0] > m[1] ? m[0] : m[1];
+    mx.bm[KB] = __builtin_bit_cast(float, ((top >> 10) + 112u) << 23);   // 2^(exponent of the largest |x|)
+}
+
 // act_stage + running block max (the f32 activations of stage 2 are at hand in stage 3)
 template <int T, int HS, bool SIG, int STAGE, bool MXT>
 __device__ __forceinline__ void act_stage_x(const f32x16 (&acc)[8], const ActIn &in, half8 (&bh)[16], half8 (&bl)[16], MxState &mx,
@@ -1642,7 +1660,8 @@ __device__ __forceinline__ float sky_pe(int k, float d0, float d1, float d2) {
     return ((k % 6) < 3) ? sinf(rad) : cosf(rad);
 }
 
-template <int DBG>
+// SMX: the four hidden layers fc2..fc5 as f16 Whi.Xhi + fp6 corrections (layer8x; nothing amplifies the sky features' error)
+template <int DBG, int SMX>
 __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1691,10 +1710,26 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
         act_step<5, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
         act_step<6, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
         act_step<7, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        if constexpr (SMX) {
+            // fc1's upper half (fragments 0..7 = K blocks 0, 1) was activated by the plain stages: block maxima from the
+            // fragments, K block 0 converted here, K block 1 by fc2's first unit (the protocol of layer8x)
+            MxState mx;
+            mx.bm[2] = mx.bm[3] = 0.f;
+            mx_block_max_f16<0>(bh, mx);
+            mx_block_max_f16<1>(bh, mx);
+            mx_convert<0>(bh, bl, mx);
 #pragma unroll 1
-        for (int l = 0; l < 4; l++)
-            layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, cst + SC_BIASH + l * HID,
-                                                l == 0 ? cst + SC_BIAS1 : cst + SC_BIASH + (l - 1) * HID, nul, h, part);
+            for (int l = 0; l < 4; l++) {
+                const float *bias = cst + SC_BIASH + l * HID, *bias_pend = l == 0 ? cst + SC_BIAS1 : cst + SC_BIASH + (l - 1) * HID;
+                if (l < 3) layer8x<DBG, 1, false, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, nul, h, part);
+                else layer8x<DBG, 2, false, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, nul, h, part);
+            }
+        } else {
+#pragma unroll 1
+            for (int l = 0; l < 4; l++)
+                layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, cst + SC_BIASH + l * HID,
+                                                    l == 0 ? cst + SC_BIAS1 : cst + SC_BIASH + (l - 1) * HID, nul, h, part);
+        }
         f32x16 col[2];
         col[0] = bias_block<0>(cst + SC_BC, h);
         col[1] = bias_block<1>(cst + SC_BC, h);
@@ -1862,6 +1897,9 @@ int sdn_field_pack_weights_mx(const float *w1, const float *const *wh5_host, con
     PackMxParams p;
     p.wh[0] = wh5_host[3];   // fc_5
     p.wh[1] = wh5_host[4];   // fc_6
+    p.wh[2] = p.wh[3] = nullptr;
+    p.n_layers = 2;
+    p.base = L0_FRAGS + 3 * LH_FRAGS;
     p.out = (half8 *)packed;
     hipLaunchKernelGGL(pack_mx_kernel, dim3(2 * 64 * 64 / 256), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_pack_weights_mx");
@@ -2005,6 +2043,17 @@ int sdn_sky_pack_weights(const float *w1, const float *const *wh4_host, const fl
     return sdn::check_launch("sdn_sky_pack_weights");
 }
 
+int sdn_sky_pack_weights_mx(const float *w1, const float *const *wh4_host, const float *wc, void *packed, sdn_stream_t stream) {
+    if (int rc = sdn_sky_pack_weights(w1, wh4_host, wc, packed, stream)) return rc;
+    PackMxParams p;
+    for (int i = 0; i < 4; i++) p.wh[i] = wh4_host[i];
+    p.n_layers = 4;
+    p.base = SKY_L0_FRAGS;
+    p.out = (half8 *)packed;
+    hipLaunchKernelGGL(pack_mx_kernel, dim3(4 * 64 * 64 / 256), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_sky_pack_weights_mx");
+}
+
 static int sky_workgroups(int32_t n_rays, int32_t n_workgroups) {
     int wg = n_workgroups > 0 ? n_workgroups : 256;
     const int groups = sdn::div_up(sdn::div_up(n_rays, 32), 4);
@@ -2014,7 +2063,7 @@ static int sky_workgroups(int32_t n_rays, int32_t n_workgroups) {
 int32_t sdn_sky_partial_rows(int32_t n_rays, int32_t n_workgroups) { return n_rays > 0 ? 4 * sky_workgroups(n_rays, n_workgroups) : 0; }
 
 int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_partial, int32_t n_rays,
-                int32_t n_workgroups, float *sky_avg, uint32_t *counter, sdn_stream_t stream) {
+                int32_t n_workgroups, float *sky_avg, uint32_t *counter, int32_t hidden_terms, sdn_stream_t stream) {
     SDN_REQUIRE(raydirs && packed && consts && sky_c && sky_partial && n_rays > 0, "sdn_sky_mlp: bad argument");
     SDN_REQUIRE((sky_avg == nullptr) == (counter == nullptr), "sdn_sky_mlp: sky_avg and counter go together");
     SkyParams p;
@@ -2023,7 +2072,9 @@ int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, f
     p.R = n_rays;
     p.n_tiles = sdn::div_up(n_rays, 32);
     const int wg = sky_workgroups(n_rays, n_workgroups);
-    hipLaunchKernelGGL(sky_kernel<0>, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    SDN_REQUIRE(hidden_terms == 3 || hidden_terms == 6, "sdn_sky_mlp: hidden_terms must be 3 or 6");
+    if (hidden_terms == 6) hipLaunchKernelGGL((sky_kernel<0, 1>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((sky_kernel<0, 0>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_sky_mlp");
 }
 

@@ -151,13 +151,15 @@ FEATURE_BUFFER_BYTES = 32 << 30   # rays are processed in chunks whose encode ->
 def precision_profile(R):
     """(colour_terms, term_eps) of the field MLP for this renderer.
 
-    colour_terms: f16 split terms of the colour layers fc_5 / fc_6 (3 = Whi.Xhi + Wlo.Xhi + Whi.Xlo like every other
-    layer; 2 = without Whi.Xlo -- nothing amplifies their error, tools/precision_study.py).
+    colour_terms: how the products of the colour layers fc_5 / fc_6 are evaluated (nothing amplifies their error,
+    tools/precision_study.py): 6 (default) = Whi.Xhi in f16 + the two correction terms as block-scaled fp6 products (error
+    equal to the full split's to 1e-6 on the goldens, half the MFMA issue slots); 3 = the 3-term f16 split like every other
+    layer; 2 = without Whi.Xlo (4-7e-4 on net_out: opt-in only).
     term_eps: early ray termination once the transmittance of all 32 rays of a workgroup is below it (0 = off);
     bounds the change of net_out by 2 * term_eps."""
     ct = getattr(R, "colour_terms", None)
     if ct is None:
-        ct = int(os.environ.get("SDN_MLP_COLOUR_TERMS", "3"))
+        ct = int(os.environ.get("SDN_MLP_COLOUR_TERMS", "6"))
     eps = getattr(R, "term_eps", None)
     if eps is None:
         eps = float(os.environ.get("SDN_TERM_EPS", "0"))
@@ -264,12 +266,14 @@ def prepare_sky(R):
     ptrs = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in wh])
     w1 = w["sky_net.fc1.weight"].contiguous()
     wc = w["sky_net.fc_out_c.weight"].contiguous()
+    packed_mx = torch.empty_like(packed)
     with torch.cuda.device(R.dev):
         capi.check(lib.sdn_sky_pack_weights(w1.data_ptr(), ptrs, wc.data_ptr(), packed.data_ptr(), _stream(R.dev)))
+        capi.check(lib.sdn_sky_pack_weights_mx(w1.data_ptr(), ptrs, wc.data_ptr(), packed_mx.data_ptr(), _stream(R.dev)))
     consts = torch.cat([w["sky_net.fc1.bias"] + R.sky_z.reshape(-1)] + [w[f"sky_net.fc{i}.bias"] for i in (2, 3, 4, 5)] +
                        [w["sky_net.fc_out_c.bias"]]).contiguous()
     assert consts.numel() == lib.sdn_sky_consts_floats()
-    R._fused_sky = dict(packed=packed, consts=consts, keep=(wh, w1, wc))
+    R._fused_sky = dict(packed=packed, packed_mx=packed_mx, consts=consts, keep=(wh, w1, wc))
     return R._fused_sky
 
 
@@ -284,8 +288,11 @@ def sky_fused(R, rd):
     sky_avg = torch.empty((1, 64), dtype=torch.float32, device=R.dev)
     if "counter" not in sk:
         sk["counter"] = torch.zeros(1, dtype=torch.int32, device=R.dev)     # the kernel leaves it at zero
+    # hidden layers fc2..fc5: 3 = 3-term f16 split (default); 6 = f16 + fp6 corrections: 1.02 -> 0.87 ms per frame, but all
+    # four hidden layers stack their ~2^-17 errors (1.1e-4 max on sky_c against 4.5e-6): opt-in
+    terms = getattr(R, "sky_terms", None) or int(os.environ.get("SDN_SKY_TERMS", "3"))
     with torch.cuda.device(R.dev):
-        capi.check(_lib().sdn_sky_mlp(rd.data_ptr(), sk["packed"].data_ptr(), sk["consts"].data_ptr(), sky_c.data_ptr(),
-                                      part.data_ptr(), n, 0, sky_avg.data_ptr(), sk["counter"].data_ptr(), _stream(R.dev)),
-                   "sdn_sky_mlp")
+        capi.check(_lib().sdn_sky_mlp(rd.data_ptr(), sk["packed_mx" if terms == 6 else "packed"].data_ptr(), sk["consts"].data_ptr(),
+                                      sky_c.data_ptr(), part.data_ptr(), n, 0, sky_avg.data_ptr(), sk["counter"].data_ptr(),
+                                      terms, _stream(R.dev)), "sdn_sky_mlp")
     return sky_c, sky_avg

@@ -226,7 +226,7 @@ class Renderer:
     def set_precision(self, cnn_terms3x3=None, colour_terms=None, term_eps=None):
         """Precision profile of the MFMA kernels (None = the default of the environment / library):
         cnn_terms3x3: f16 product terms of the four 3x3 convolutions, 1 (default) or 3 (cnn.py);
-        colour_terms: split terms of the colour layers fc_5 / fc_6, 3 (default) or 2 (fused.precision_profile);
+        colour_terms: products of the colour layers fc_5 / fc_6: 6 (default: f16 + fp6 corrections), 3 or 2 (fused.precision_profile);
         term_eps: early ray termination threshold on the transmittance, 0 = off (default)."""
         self.cnn_terms3x3, self.colour_terms, self.term_eps = cnn_terms3x3, colour_terms, term_eps
         self._mfma_cnn = None
@@ -238,7 +238,8 @@ class Renderer:
         ct, _ = fused.precision_profile(self)
         t3 = getattr(self, "cnn_terms3x3", None) or int(os.environ.get("SDN_CNN_TERMS", "1"))
         return (f"f32 (hash grid) + f16 MFMA with f32 accumulate: field/sky MLP 3-term split"
-                f"{' (colour layers 2-term)' if ct == 2 else ''}, render CNN 1x1 3-term / 3x3 {t3}-term")
+                f"{' (colour layers 2-term)' if ct == 2 else ' (colour layers: f16 Whi.Xhi + MX-fp6 corrections)' if ct == 6 else ''}"
+                f", render CNN 1x1 3-term / 3x3 {t3}-term")
 
     def measure_roofline(self, pose, resolution_hw, num_samples, mode, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0):
         """Roofline records, timed with events on the launch stream (PyTorch's current stream).
@@ -331,8 +332,12 @@ class Renderer:
         # hit nothing and the passes early termination removes): samples of skipped groups are not work done.
         n_eval = ev["evaluated_samples"]
         ach_m = n_eval * 754176 / (ms_mlp * 1e-3) / 1e12
-        issued = (2208 - (256 if ct == 2 else 0)) / 736.0     # MFMAs per pass / algorithmic (one per product tile)
-        mlp = {"bound": "mfma", "kernel": f"mlp_kernel (f16 MFMA, 3-term split, colour layers {ct}-term, f32 accumulate)",
+        # MFMA issue slots per pass / algorithmic (one f16 MFMA per product tile): 2208 for the 3-term split everywhere;
+        # colour layers 2-term: 2 x 128 fewer; colour layers f16 + fp6: 2 x (384 - 192) fewer (an fp6 K = 64 MFMA takes the
+        # issue time of one K = 16 f16 MFMA)
+        issued = (2208 - (256 if ct == 2 else 384 if ct == 6 else 0)) / 736.0
+        colour = {2: "2-term", 3: "3-term", 6: "f16 + MX-fp6 corrections"}[ct]
+        mlp = {"bound": "mfma", "kernel": f"mlp_kernel (f16 MFMA, 3-term split, colour layers {colour}, f32 accumulate)",
                "achieved": ach_m, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach_m / mfma_peak_tflops,
                "traffic": traffic.get("mlp_kernel"), "traffic_source": traffic_src,
                "samples_per_launch": B, "samples_evaluated": n_eval, "algorithmic_flop_per_sample": 754176,
@@ -342,8 +347,9 @@ class Renderer:
                "timing": timing,
                "achieved_counting_skipped_samples": B * 754176 / (ms_mlp * 1e-3) / 1e12,
                "note": "achieved = samples evaluated x 754 176 FLOP / launch time (skipped sky groups are not counted as "
-                       "work); the kernel issues `issued_over_algorithmic` f16 MFMAs per algorithmic product (hi*hi + "
-                       "lo*hi + hi*lo: plain f16 misses the 1e-3 bound 17x); traffic = HBM bytes per launch from the "
+                       "work); the kernel issues `issued_over_algorithmic` MFMA slots per algorithmic product (hi*hi + "
+                       "lo*hi + hi*lo: plain f16 misses the 1e-3 bound 17x; in the colour layers the two corrections run as "
+                       "block-scaled fp6 at 4x the rate); traffic = HBM bytes per launch from the "
                        "PMC profile named in traffic_source (a separate rocprofv3 --pmc run, not this process)"}
         return mlp, grid
 

@@ -137,6 +137,13 @@ def test_sky_mlp_kernel_matches_torch(renderer):
     got, avg = fused.sky_fused(renderer, rd)
     assert (got - ref).abs().max().item() < 2e-4
     assert (avg - ref.mean(dim=0, keepdim=True)).abs().max().item() < 2e-5
+    # opt-in: hidden layers fc2..fc5 as f16 Whi.Xhi + block-scaled fp6 corrections (the field MLP's colour-layer scheme)
+    try:
+        renderer.sky_terms = 6
+        got6, avg6 = fused.sky_fused(renderer, rd)
+    finally:
+        renderer.sky_terms = None
+    assert (got6 - ref).abs().max().item() < 2e-4 and (avg6 - ref.mean(dim=0, keepdim=True)).abs().max().item() < 2e-5
 
 
 def test_sample_depth_op_matches_reference_golden():

@@ -153,9 +153,10 @@ def test_row_bands_reproduce_the_full_frame(renderer, scene256, mode):
 # ---------------------------------------------------------------------------------------------------- precision profile
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_colour_layers_two_term_within_budget(renderer, tag):
-    """fc_5 / fc_6 without their Whi.Xlo products (colour_terms = 2, 11.6 % fewer MFMAs in mlp_kernel): net_out and
-    image against the goldens recorded from the unmodified reference, same 1e-3 bound; the measured error is printed
-    beside the 3-term kernel's."""
+    """The three evaluations of the colour layers fc_5 / fc_6 against the goldens recorded from the unmodified reference,
+    same 1e-3 bound, measured errors printed side by side: 3 = the 3-term f16 split; 2 = without the Whi.Xlo products
+    (11.6 % fewer MFMAs, opt-in); 6 = Whi.Xhi in f16 + block-scaled fp6 corrections (the default: 17 % fewer MFMA issue
+    slots, error indistinguishable from the 3-term kernel's)."""
     from scenedreamer_amd import fused
     g = golden(f"field_{tag}.npz")
     vid, d2, rd, ori, sky_avg = _inputs(g)

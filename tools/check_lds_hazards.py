@@ -19,7 +19,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = {"field.hip": ["-fno-slp-vectorize"], "cnn.hip": []}
-KERNELS = ("mlp_kernelILi0ELi3", "mlp_kernelILi0ELi2", "mlp_kernelILi0ELi6", "sky_kernelILi0", "conv_kernelILi9ELi0ELi3", "conv_kernelILi9ELi0ELi1", "conv_kernelILi1ELi0ELi3")
+KERNELS = ("mlp_kernelILi0ELi3", "mlp_kernelILi0ELi2", "mlp_kernelILi0ELi6", "sky_kernelILi0ELi0", "sky_kernelILi0ELi1", "conv_kernelILi9ELi0ELi3", "conv_kernelILi9ELi0ELi1", "conv_kernelILi1ELi0ELi3")
 REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 
 
