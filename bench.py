@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extra loops (other apron setting, delivered rate): for the very large configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", action="store_true",
+                    help="for rocprofv3 --kernel-trace runs: only launches of the benchmark configuration (no other-apron / "
+                         "delivered-rate loops, no stand-alone kernel timing, no CPU baseline), so that the trace's average "
+                         "duration of a kernel is the average over the same launches the roofline record uses")
     ap.add_argument("--cpu-budget-s", type=float, default=25.0)
     ap.add_argument("--cam-maxstep", type=int, default=40, help="poses of the pattern-0 orbit (reference cam_maxstep)")
     ap.add_argument("--pose-stride", type=int, default=2, help="frame f uses pose (stride * f) %% cam_maxstep")
@@ -78,6 +82,8 @@ def parse():
     ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
                     help="BASELINE.json configs[i-1]: sets resolution / samples / cam_maxstep / bench mode / steps")
     args = ap.parse_args()
+    if args.profile:
+        args.no_extras = args.no_cpu_baseline = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.config == 3:
         args.height, args.width, args.samples, args.no_extras = 1080, 1920, 40, True
@@ -288,11 +294,12 @@ def main():
             timing=f"HIP events around each of the {len(probe['mlp_kernel'])} launches of the timed region, on the launch stream "
                    "(mlp_kernel: main; encode_kernel: side stream, where it shares the GPU with the previous frame's "
                    "mlp_kernel / conv_kernel -- its stand-alone duration is `standalone_ms`)")
-        alone = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
-        roof["standalone_ms"], roof_grid["standalone_ms"] = alone[0]["avg_launch_ms"], alone[1]["avg_launch_ms"]
-        roof["standalone_note"] = roof_grid["standalone_note"] = (
-            "standalone_ms: 5 back-to-back launches of the kernel alone on the whole padded frame "
-            f"({alone[0]['samples_per_launch']} samples), outside the timed region")
+        if not args.profile:
+            alone = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
+            roof["standalone_ms"], roof_grid["standalone_ms"] = alone[0]["avg_launch_ms"], alone[1]["avg_launch_ms"]
+            roof["standalone_note"] = roof_grid["standalone_note"] = (
+                "standalone_ms: 5 back-to-back launches of the kernel alone on the whole padded frame "
+                f"({alone[0]['samples_per_launch']} samples), outside the timed region")
     else:
         roof, roof_grid = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
 
