@@ -147,6 +147,27 @@ def grid_encode_fwd(inputs, embeddings, offsets, S, H, calc_grad_inputs=False, g
     return (out, dy_dx) if calc_grad_inputs else out
 
 
+def grid_encode_fwd_f16(inputs, embeddings, offsets, S, H, calc_grad_inputs=False, gridtype=0, align_corners=False):
+    """Oracle of _gridencoder.grid_encode_forward with a half table (scalar_t = at::Half: half accumulators, every
+    product and sum rounded to half, gridencoder.cu:140-176, :181-223).  embeddings: float16 (or floats holding half
+    values).  Returns outputs [L,B,C] float16 (and dy_dx [B, L*D*C] float16)."""
+    inputs = _f32(inputs)
+    emb = np.ascontiguousarray(np.asarray(embeddings, np.float16).astype(np.float32))
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    B, D = inputs.shape
+    C = emb.shape[1]
+    L = offsets.size - 1
+    out = np.empty((L, B, C), np.float32)
+    dy_dx = np.empty((B, L * D * C), np.float32) if calc_grad_inputs else None
+    lib().oracle_grid_encode_fwd_f16(_p(inputs), _p(emb), _p(offsets), _p(out), ctypes.c_uint32(B),
+                                     ctypes.c_uint32(D), ctypes.c_uint32(C), ctypes.c_uint32(L), ctypes.c_float(S),
+                                     ctypes.c_uint32(H), ctypes.c_int(int(calc_grad_inputs)),
+                                     _p(dy_dx) if calc_grad_inputs else None, ctypes.c_uint32(gridtype),
+                                     ctypes.c_int(int(align_corners)))
+    out = out.astype(np.float16)
+    return (out, dy_dx.astype(np.float16)) if calc_grad_inputs else out
+
+
 def round_half(x):
     """float32 -> nearest-even half precision value, returned as float32 (oracle's own rounding routine)."""
     lib().oracle_round_half.restype = ctypes.c_float

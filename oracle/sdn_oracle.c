@@ -236,13 +236,18 @@ ORACLE_API void oracle_level_params(uint32_t level, float S, uint32_t H, float *
     *resolution = (uint32_t)ceil(*scale) + 1;      /* :127 */
 }
 
-/* kernel_grid<float,D,C>: gridencoder.cu:75-224.
+static float f16r(float x);   /* float -> nearest-even half value (defined with the f16 backward below) */
+
+/* kernel_grid<scalar_t,D,C>: gridencoder.cu:75-224.
  * inputs [B,D] in [0,1]; grid [sO,C]; offsets [L+1]; outputs [L,B,C];
- * dy_dx [B,L,D,C] when calc_grad_inputs.                                     */
-ORACLE_API void oracle_grid_encode_fwd(const float *inputs, const float *grid_all, const int32_t *offsets,
-                                       float *outputs_all, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
-                                       float S, uint32_t H, int calc_grad_inputs, float *dy_dx_all,
-                                       uint32_t gridtype, int align_corners) {
+ * dy_dx [B,L,D,C] when calc_grad_inputs.
+ * half != 0: scalar_t = at::Half.  `results` / `results_grad` are halves there (:143, :184): every `+= w * grid[..]`
+ * rounds the float product to half (implicit Half(float)) and then the half + half sum (c10::Half operator+), and
+ * `grid[r] - grid[l]` is a half subtraction; the grid / outputs are passed as floats holding half values.          */
+static void grid_fwd_impl(const float *inputs, const float *grid_all, const int32_t *offsets,
+                          float *outputs_all, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                          float S, uint32_t H, int calc_grad_inputs, float *dy_dx_all,
+                          uint32_t gridtype, int align_corners, int half) {
     for (uint32_t level = 0; level < L; level++) {
         const float *grid = grid_all + (size_t)(uint32_t)offsets[level] * C;
         const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
@@ -278,7 +283,10 @@ ORACLE_API void oracle_grid_encode_fwd(const float *inputs, const float *grid_al
                     else { w *= pos[d]; pgl[d] = pos_grid[d] + 1; }
                 }
                 uint32_t index = get_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
-                for (uint32_t ch = 0; ch < C; ch++) results[ch] += w * grid[index + ch];
+                for (uint32_t ch = 0; ch < C; ch++) {
+                    if (half) results[ch] = f16r(results[ch] + f16r(w * grid[index + ch]));
+                    else results[ch] += w * grid[index + ch];
+                }
             }
             for (uint32_t ch = 0; ch < C; ch++) outputs[ch] = results[ch];
             if (dy_dx) { /* :181-223 */
@@ -296,13 +304,30 @@ ORACLE_API void oracle_grid_encode_fwd(const float *inputs, const float *grid_al
                         uint32_t il = get_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
                         pgl[gd] = pos_grid[gd] + 1;
                         uint32_t ir = get_grid_index(D, C, gridtype, align_corners, 0, hashmap_size, resolution, pgl);
-                        for (uint32_t ch = 0; ch < C; ch++) rg[ch] += w * (grid[ir + ch] - grid[il + ch]);
+                        for (uint32_t ch = 0; ch < C; ch++) {
+                            if (half) rg[ch] = f16r(rg[ch] + f16r(w * f16r(grid[ir + ch] - grid[il + ch])));
+                            else rg[ch] += w * (grid[ir + ch] - grid[il + ch]);
+                        }
                     }
                     for (uint32_t ch = 0; ch < C; ch++) dy_dx[gd * C + ch] = rg[ch];
                 }
             }
         }
     }
+}
+
+ORACLE_API void oracle_grid_encode_fwd(const float *inputs, const float *grid_all, const int32_t *offsets,
+                                       float *outputs_all, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                       float S, uint32_t H, int calc_grad_inputs, float *dy_dx_all,
+                                       uint32_t gridtype, int align_corners) {
+    grid_fwd_impl(inputs, grid_all, offsets, outputs_all, B, D, C, L, S, H, calc_grad_inputs, dy_dx_all, gridtype, align_corners, 0);
+}
+
+ORACLE_API void oracle_grid_encode_fwd_f16(const float *inputs, const float *grid_all, const int32_t *offsets,
+                                           float *outputs_all, uint32_t B, uint32_t D, uint32_t C, uint32_t L,
+                                           float S, uint32_t H, int calc_grad_inputs, float *dy_dx_all,
+                                           uint32_t gridtype, int align_corners) {
+    grid_fwd_impl(inputs, grid_all, offsets, outputs_all, B, D, C, L, S, H, calc_grad_inputs, dy_dx_all, gridtype, align_corners, 1);
 }
 
 /* kernel_grid_backward (:227-314) + kernel_input_backward (:317-343), float only.

@@ -176,6 +176,28 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t w, uint32_t n) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// float -> nearest half value, as a float (the empty asm keeps hipcc from fusing the round trip into a wider expression)
+__device__ __forceinline__ float round_h(float x) {
+    float r = __half2float(__float2half(x));
+    asm("" : "+v"(r));
+    return r;
+}
+
+// `results[ch] += w * value` in the reference's scalar_t arithmetic (gridencoder.cu:143, :170; :184, :215).
+// float: as written.  at::Half: `results` is a half -- the float product is rounded to half by the implicit Half(float),
+// then the half + half sum rounds again (c10::Half operator+); bit-identical to the reference's own kernel compiled for
+// the host (tests/test_ref_pin_cpu.py::test_grid_forward_half_oracle_equals_reference_source).
+template <typename T>
+__device__ __forceinline__ void acc_scalar_t(float &res, float w, float v) {
+    if constexpr (sizeof(T) == 2) {
+        float p = w * v;            // a float product first (rounded to f32): fused into the conversion (v_fma_mixlo_f16) it would
+        asm("" : "+v"(p));          // round ONCE to half and differ from the reference's two roundings by an ulp now and then
+        res = round_h(res + round_h(p));
+    } else {
+        res += w * v;
+    }
+}
+
 template <typename T, uint32_t D, uint32_t C>
 __global__ __launch_bounds__(FWD_THREADS) void grid_fwd_kernel(const float *__restrict__ inputs,
                                                               const T *__restrict__ grid,
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(FWD_THREADS) void grid_fwd_kernel(const float *__re
         float v[C];
         load_row<C>(grid + (uint64_t)row * C, v);
 #pragma unroll
-        for (uint32_t c = 0; c < C; c++) res[c] += w * v[c];
+        for (uint32_t c = 0; c < C; c++) acc_scalar_t<T>(res[c], w, v[c]);
     }
     store_row<C>(out, res);
 
@@ -288,7 +310,8 @@ __global__ __launch_bounds__(FWD_THREADS) void grid_fwd_kernel(const float *__re
                 load_row<C>(grid + (uint64_t)rl * C, vl);
                 load_row<C>(grid + (uint64_t)rr * C, vr);
 #pragma unroll
-                for (uint32_t c = 0; c < C; c++) rg[c] += w * (vr[c] - vl[c]);
+                for (uint32_t c = 0; c < C; c++)   // at::Half: grid[right] - grid[left] is a half subtraction
+                    acc_scalar_t<T>(rg[c], w, sizeof(T) == 2 ? round_h(vr[c] - vl[c]) : vr[c] - vl[c]);   // (half - half is exact in f32)
             }
 #pragma unroll
             for (uint32_t c = 0; c < C; c++) dd[gd * C + c] = (T)rg[c];

@@ -281,3 +281,77 @@ def test_ray_window_equals_sliced_copies(renderer):
     finally:
         fused.FEATURE_BUFFER_BYTES = old
     assert torch.equal(chunked, whole)
+
+
+# ---------------------------------------------------------------------------------------------------- MX fp6 colour layers
+def test_mx_fp6_hardware_facts():
+    """tools/mx_probe (built by __graft_entry__.build): element order / scale semantics / rounding of the fp6 conversions and
+    the operand layout + per-lane E8M0 scale bytes of v_mfma_scale_f32_32x32x64_f8f6f4, as layer8x and pack_mx_kernel assume."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mx_probe")
+    if not os.path.exists(exe):
+        pytest.skip("tools/mx_probe not built")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    lines = out.splitlines()
+    nat = " ".join(str(i) for i in range(32)).replace(" 5 ", " 37 ")          # element 5 is negative in the probe
+    inter = " ".join(str(v) for i in range(16) for v in (i, 16 + i)).replace(" 5 ", " 37 ")
+    for sc in ("1", "2", "0.5", "3"):
+        assert any(l.startswith(f"cvt pk32_fp6_f16   scale {sc} ") and l.rstrip().endswith(nat) for l in lines), sc
+        assert any(l.startswith(f"cvt 2xpk16_fp6_f32 scale {sc} ") and l.rstrip().endswith(inter) for l in lines), sc
+    assert sum("wrong codes pk32_fp6_f16 0, 2xpk16_fp6_f32 0" in l for l in lines) == 4
+    assert sum(l.startswith("mfma_scale fp6 test") and l.rstrip().endswith("OK") for l in lines) == 6 and "MISMATCH" not in out
+    # round to nearest even, saturating at 7.5 (element i of the awkward inputs sits at position 2 i)
+    rnd = next(l for l in lines if l.startswith("rounding"))
+    got = {int(t[1:t.index("]")]): float(t.split("=")[1]) for t in rnd.split() if t.startswith("[")}
+    want = [7.5, 7.5, 7.5, 7.5, 7.5, 0.0, 0.125, 0.25, 0.25, 3.75, 4.0, 1.0, 1.125, -7.5, 0.0, 6.0]
+    assert [got[2 * i] for i in range(16)] == want
+
+
+def test_mx_weight_image_decodes_to_the_weights(renderer):
+    """pack_mx_kernel: the colour layers' part of the packed weight stream (f16 Whi fragments of a k-step for four row
+    blocks; fp6 fragments of Wlo and Whi with one E8M0 scale per row and 32-k block) decoded on the host equals the folded
+    weights: Whi exactly, the fp6 parts to half an fp6 step of the block maximum."""
+    from scenedreamer_amd import fused
+    renderer.set_style_code(golden("field_a.npz")["z"])
+    st = fused.prepare_style(renderer)
+    torch.cuda.synchronize()
+    raw = st["packed_mx"].cpu().numpy().view(np.uint32)
+    L0, LH = 8 * 8 * 2 * 64, 16 * 8 * 2 * 64                     # fragments (16 bytes per lane) of fc_1 / of a hidden layer
+
+    def dec6(c):
+        c = np.asarray(c, np.int64)
+        sg, e, m = (c >> 5) & 1, (c >> 3) & 3, c & 7
+        v = np.where(e == 0, m * 0.125, (1 + m * 0.125) * np.exp2(e - 1.0))
+        return np.where(sg == 1, -v, v)
+
+    kmap = lambda s_, h, e: 32 * (s_ >> 1) + 16 * (s_ & 1) + (e & 3) + 8 * (e >> 2) + 4 * h
+    worst = {0: 0.0, 1: 0.0}
+    for layer, name in ((0, 5), (1, 6)):
+        W = renderer.mod[name][0].cpu().numpy().astype(np.float32) * np.float32(0.4)
+        Whi = W.astype(np.float16).astype(np.float32)
+        Wlo = W - Whi
+        base = (L0 + (3 + layer) * LH) * 4
+        for u in range(0, 64, 3):
+            half, kb, sub, ib0 = u // 32, (u % 32) // 8, u % 8, 4 * (u // 32)
+            ub = base + u * 4 * 64 * 4
+            for lane in (0, 5, 31, 32, 63):
+                h = lane >> 5
+                frag = lambda f: raw[ub + (f * 64 + lane) * 4: ub + (f * 64 + lane) * 4 + 4]
+                if sub < 4:
+                    for f in range(4):
+                        row = 32 * (ib0 + f) + (lane & 31)
+                        ref = np.array([Whi[row, kmap(4 * kb + sub, h, e)] for e in range(8)])
+                        np.testing.assert_array_equal(frag(f).view(np.float16).astype(np.float32), ref)
+                    continue
+                term, iba = (sub - 4) // 2, ib0 + 2 * ((sub - 4) % 2)
+                for rb in range(2):
+                    f0, f1 = frag(2 * rb), frag(2 * rb + 1)
+                    big = sum(int(v) << (32 * i) for i, v in enumerate(list(f0) + list(f1[:2])))
+                    val = dec6([(big >> (6 * i)) & 63 for i in range(32)]) * np.exp2(float(int(f1[2]) - 127))
+                    row = 32 * (iba + rb) + (lane & 31)
+                    ref = np.array([(Wlo if term == 0 else Whi)[row, kmap(4 * kb + i // 8, h, i % 8)] for i in range(32)])
+                    # (the sign of an exact f16 rounding tie of Wlo is the device's; magnitudes are compared)
+                    err = np.abs(np.abs(val) - np.abs(ref)).max() / max(np.abs(ref).max(), 1e-30)
+                    worst[term] = max(worst[term], float(err))
+    assert worst[0] < 0.07 and worst[1] < 0.07, worst            # fp6 step in the top binade: 0.5 / 7.5 of the block maximum

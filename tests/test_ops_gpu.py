@@ -215,15 +215,21 @@ def test_grid_forward_scenedreamer_config(ops, oracle):
 
 
 def test_grid_forward_half_table(ops, oracle):
-    offs, emb, x, S = _grid_case(3, 4, 5, 10, 4, 1.6, 0, False, 1500, 77)
-    emb16 = torch.from_numpy(emb).half()
-    out = torch.empty(5, x.shape[0], 4, device="cuda", dtype=torch.half)
-    dy = torch.empty(1, device="cuda", dtype=torch.half)
-    ops.grid_encode_forward(torch.from_numpy(x).cuda(), emb16.cuda(), torch.from_numpy(offs).cuda(), out, x.shape[0],
-                            3, 4, 5, S, 4, False, dy, 0, False)
-    ref = oracle.grid_encode_fwd(x, emb16.float().numpy(), offs, S, 4)
-    # f16 table, f32 blend, one final rounding to f16: half an f16 ulp at |v|<=0.5 is 1.2e-4
-    np.testing.assert_allclose(out.float().cpu().numpy(), ref, rtol=0, atol=3e-4)
+    """scalar_t = at::Half (gridencoder.cu:140-176, :181-223): `results` / `results_grad` are halves, every product and sum
+    rounds to half.  Features and dy_dx bit for bit against the oracle's emulation, which is pinned on the reference's own
+    kernel (tests/test_ref_pin_cpu.py)."""
+    for (D, C, L, T, H, pls, gt, ac, B, seed) in ((3, 4, 5, 10, 4, 1.6, 0, False, 1500, 77), (5, 8, 4, 14, 16, 1.4, 0, False, 900, 5),
+                                                  (2, 2, 3, 10, 4, 1.5, 1, True, 700, 6)):
+        offs, emb, x, S = _grid_case(D, C, L, T, H, pls, gt, ac, B, seed)
+        x[::40] = 1.2                                       # out-of-range rows
+        emb16 = torch.from_numpy(emb).half()
+        out = torch.empty(L, B, C, device="cuda", dtype=torch.half)
+        dy = torch.empty(B, L * D * C, device="cuda", dtype=torch.half)
+        ops.grid_encode_forward(torch.from_numpy(x).cuda(), emb16.cuda(), torch.from_numpy(offs).cuda(), out, B,
+                                D, C, L, S, H, True, dy, gt, ac)
+        ref, ref_dy = oracle.grid_encode_fwd_f16(x, emb16.numpy(), offs, S, H, True, gt, ac)
+        np.testing.assert_array_equal(out.cpu().numpy().view(np.uint16), ref.view(np.uint16))
+        np.testing.assert_array_equal(dy.cpu().numpy().view(np.uint16), ref_dy.view(np.uint16))
 
 
 def test_grid_backward(ops, oracle):

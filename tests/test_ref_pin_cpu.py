@@ -111,6 +111,25 @@ def test_grid_encode_oracle_equals_reference_source(oracle, ref, case):
     np.testing.assert_allclose(gia, gib, rtol=0, atol=1e-4 * max(1.0, float(np.abs(gib).max())))
 
 
+def test_grid_forward_half_oracle_equals_reference_source(oracle, ref):
+    """scalar_t = at::Half forward (gridencoder.cu:140-176: `scalar_t results[C]`, `results[ch] += w * grid[..]` rounds the
+    product and the sum to half; dy_dx :181-223 likewise with a half subtraction): the oracle's emulation gives the bits
+    the reference's own kernel produces, features and dy_dx."""
+    from scenedreamer_amd.gridencoder import level_offsets
+    rng = np.random.default_rng(2)
+    for (D, C, L, H, pls, T, gt, ac) in [(3, 2, 4, 4, 1.7, 12, 0, False), (5, 8, 4, 16, 1.4, 14, 0, False), (2, 4, 3, 4, 1.5, 10, 1, True),
+                                         (4, 1, 3, 8, 1.3, 11, 0, True)]:
+        offs = level_offsets(D, L, pls, H, T, ac)
+        emb = (rng.random((int(offs[-1]), C), dtype=np.float32) - 0.5).astype(np.float16)
+        x = rng.random((700, D), dtype=np.float32)
+        x[::50] = -0.1                                   # out-of-range rows
+        S = np.float32(np.log2(pls))
+        ro, rd = ref.grid_encode_fwd(x, emb, offs, S, H, True, gt, ac, dtype=np.float16)
+        oo, od = oracle.grid_encode_fwd_f16(x, emb, offs, S, H, True, gt, ac)
+        np.testing.assert_array_equal(ro.view(np.uint16), oo.view(np.uint16))
+        np.testing.assert_array_equal(rd.view(np.uint16), od.view(np.uint16))
+
+
 def test_grid_backward_half_oracle_equals_reference_source(oracle, ref):
     """scalar_t = at::Half through the reference's own kernels (gridencoder.cu:296-304 __half2 atomics, :317-343):
     the oracle's half emulation gives the same grad_inputs bits; the table gradients agree to half-precision
