@@ -106,3 +106,43 @@ def test_config1_frame_against_cpu_oracle(lut):
                                 (128, 128), 12, R.z.cpu().numpy(), R.global_enc.cpu().numpy())
     err = np.abs(img.cpu().numpy() - ref.numpy())
     assert err.max() < 1e-3, f"max abs err {err.max():.3e}"
+
+
+def test_trajectory_to_png_and_mp4_keeps_pace(big, tmp_path):
+    """The output stage beside the renderer (scenedreamer.py:560, :629-632): a pipelined 960x540 trajectory
+    handed to FrameWriter (uint8 conversion on the GPU, async D2H on a side stream, PNG pool + MJPEG-MP4 thread).  Every
+    frame arrives in both outputs with the renderer's pixels, and the delivered rate -- files closed -- stays within
+    the render-only rate's neighbourhood instead of the synchronous writer's ~10 frames/s."""
+    import time
+
+    import numpy as np
+    from PIL import Image
+    from scenedreamer_amd.mp4 import read_frames
+    from scenedreamer_amd.output import FrameWriter, to_uint8_hwc
+    R, scene, poses = big
+    sel = [poses[(3 * i) % 40] for i in range(16)]
+    for _ in R.render_frames(sel[:3], (540, 960), 24, mode="fused"):     # warm-up
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in R.render_frames(sel, (540, 960), 24, mode="fused"):
+        pass
+    torch.cuda.synchronize()
+    render_fps = len(sel) / (time.perf_counter() - t0)
+    w = FrameWriter(str(tmp_path / "png"), fmt="png", video_path=str(tmp_path / "out.mp4"), fps=10)
+    keep = {}
+    t0 = time.perf_counter()
+    for i, img in enumerate(R.render_frames(sel, (540, 960), 24, mode="fused")):
+        w.submit(img, i)
+        if i in (0, 9):
+            keep[i] = to_uint8_hwc(img).cpu().numpy()
+    w.close()
+    delivered_fps = len(sel) / (time.perf_counter() - t0)
+    print(f"render only {render_fps:.1f} frames/s, delivered as PNG + MP4 {delivered_fps:.1f} frames/s")
+    assert w.frames_done == len(sel)
+    for i, ref in keep.items():
+        np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "png" / f"{i:05d}.png")), ref)
+    fps, frames = read_frames(str(tmp_path / "out.mp4"))
+    assert fps == 10 and len(frames) == len(sel)
+    assert np.abs(frames[9].astype(np.int32) - keep[9].astype(np.int32)).mean() < 4.0      # JPEG
+    assert delivered_fps > 0.5 * render_fps and delivered_fps > 15.0
