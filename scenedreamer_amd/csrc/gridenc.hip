@@ -25,6 +25,8 @@
 
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "sdn_common.h"
 
 namespace {
@@ -319,6 +321,102 @@ __global__ __launch_bounds__(FWD_THREADS) void grid_fwd_kernel(const float *__re
     }
 }
 
+// Forward without dy_dx, f32 tables (inference: what GridEncoder.forward runs in the un-fused path), wave-cooperative:
+// FOUR lanes share one (sample, level).  Lane q of the quad takes the corners whose two lowest dimension bits are q --
+// 2^(D-2) rows of C floats in flight per lane instead of 2^D behind one another, 4x the waves to hide the L2 / Infinity
+// Cache latency of the gathers -- blends them with the reference's weights (same factor order per corner), and the four
+// partial rows are added with two DPP quad permutes.  Each lane then stores its C/4 channels: one coalesced row per quad.
+// Only the summation order differs from the reference (grouped by quad lane instead of corner order: <= a few ulp).
+template <int CTRL>
+__device__ __forceinline__ float quad_add(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+    return v + __builtin_bit_cast(float, o);
+}
+
+template <uint32_t D, uint32_t C>
+__global__ __launch_bounds__(FWD_THREADS) void grid_fwd_quad_kernel(const float *__restrict__ inputs,
+                                                                   const float *__restrict__ grid,
+                                                                   const int32_t *__restrict__ offsets,
+                                                                   float *__restrict__ outputs, uint32_t B, uint32_t L, float S,
+                                                                   uint32_t H, uint32_t gridtype, bool align_corners,
+                                                                   const GridLevels lv) {
+    static_assert(D >= 2, "two dimensions are split over the quad");
+    const uint32_t blk = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t q = threadIdx.x & 3;
+    const uint64_t b0 = (uint64_t)blk * (FWD_THREADS / 4) + (threadIdx.x >> 2);
+    const bool live = b0 < B;                      // whole quads are live or not; dead lanes follow along for the DPP adds
+    const uint64_t b = live ? b0 : (uint64_t)B - 1;
+    const uint32_t level = blockIdx.y;
+    grid += (uint64_t)(uint32_t)offsets[level] * C;
+    const float *in = inputs + b * D;
+
+    float x[D];
+    bool oob = false;
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        x[d] = in[d];
+        oob |= (x[d] < 0 || x[d] > 1);  // gridencoder.cu:99-106
+    }
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    float scale;
+    uint32_t resolution;
+    level_params(lv, level, S, H, scale, resolution);
+    const uint32_t dim_stride = align_corners ? resolution : resolution + 1;
+    float pos[D];
+    uint32_t pg[D];
+#pragma unroll
+    for (uint32_t d = 0; d < D; d++) {
+        pos[d] = mul_add_exact(oob ? 0.f : x[d], scale, align_corners ? 0.0f : 0.5f);
+        const float fl = floorf(pos[d]);
+        pg[d] = (uint32_t)fl;
+        pos[d] -= (float)pg[d];
+    }
+    float res[C];
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) res[c] = 0.f;
+#pragma unroll
+    for (uint32_t hi = 0; hi < (1u << (D - 2)); hi++) {
+        const uint32_t idx = (hi << 2) | q;
+        float w = 1.f;
+        uint32_t pgl[D];
+#pragma unroll
+        for (uint32_t d = 0; d < D; d++) {   // the reference's factor order, :152-160
+            if ((idx & (1u << d)) == 0) {
+                w *= 1 - pos[d];
+                pgl[d] = pg[d];
+            } else {
+                w *= pos[d];
+                pgl[d] = pg[d] + 1;
+            }
+        }
+        const uint32_t row = grid_row<D>(pgl, gridtype, dim_stride, hashmap_size);
+        float v[C];
+        load_row<C>(grid + (uint64_t)row * C, v);
+#pragma unroll
+        for (uint32_t c = 0; c < C; c++) res[c] += w * v[c];
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < C; c++) {
+        res[c] = quad_add<0xB1>(res[c]);   // quad_perm [1,0,3,2]
+        res[c] = quad_add<0x4E>(res[c]);   // quad_perm [2,3,0,1]
+        if (oob) res[c] = 0.f;
+    }
+    if (!live) return;
+    float *out = outputs + ((uint64_t)level * B + b) * C;
+    if constexpr (C == 8) {
+        // lane q stores channels 2q, 2q+1 (a constant-index select chain: no dynamic register indexing)
+        const float lo = q == 0 ? res[0] : q == 1 ? res[2] : q == 2 ? res[4] : res[6];
+        const float hi = q == 0 ? res[1] : q == 1 ? res[3] : q == 2 ? res[5] : res[7];
+        *reinterpret_cast<float2 *>(out + 2 * q) = make_float2(lo, hi);
+    } else if constexpr (C == 4) {
+        out[q] = q == 0 ? res[0] : q == 1 ? res[1] : q == 2 ? res[2] : res[3];
+    } else if constexpr (C == 2) {
+        if (q < 2) out[q] = q == 0 ? res[0] : res[1];
+    } else {
+        if (q == 0) out[0] = res[0];
+    }
+}
+
 // Scatter of output gradients into the table: one lane per (sample, level),
 // all C channels (the reference uses N_C = 2 channels per thread; with f32
 // hardware atomics a full 32 B row per lane keeps the L2 atomic units fed with
@@ -451,6 +549,24 @@ int launch_fwd_c(const float *inputs, const T *emb, const int32_t *offsets, T *o
     const dim3 grid(sdn::div_up<uint32_t>(B, FWD_THREADS), L, 1);
     const dim3 block(FWD_THREADS);
     const GridLevels lv = make_levels(L, S, H);
+    if constexpr (sizeof(T) == 4) {
+        // inference form (f32 table, no dy_dx): the quad-cooperative kernel.  SDN_GRID_QUAD=0 keeps the one-lane-per-(sample,
+        // level) kernel for A/B measurements.
+        static const bool quad = [] { const char *e = getenv("SDN_GRID_QUAD"); return !(e && e[0] == '0'); }();
+        if (quad && !cg) {
+            const dim3 gq(sdn::div_up<uint32_t>(B, FWD_THREADS / 4), L, 1);
+            const float *embf = (const float *)emb;
+            float *outf = (float *)out;
+            switch (C) {
+                case 1: hipLaunchKernelGGL((grid_fwd_quad_kernel<D, 1>), gq, block, 0, st, inputs, embf, offsets, outf, B, L, S, H, gridtype, ac, lv); break;
+                case 2: hipLaunchKernelGGL((grid_fwd_quad_kernel<D, 2>), gq, block, 0, st, inputs, embf, offsets, outf, B, L, S, H, gridtype, ac, lv); break;
+                case 4: hipLaunchKernelGGL((grid_fwd_quad_kernel<D, 4>), gq, block, 0, st, inputs, embf, offsets, outf, B, L, S, H, gridtype, ac, lv); break;
+                case 8: hipLaunchKernelGGL((grid_fwd_quad_kernel<D, 8>), gq, block, 0, st, inputs, embf, offsets, outf, B, L, S, H, gridtype, ac, lv); break;
+                default: return sdn::fail(SDN_ERR_UNSUPPORTED, "GridEncoding: C must be 1, 2, 4, or 8.");
+            }
+            return sdn::check_launch("sdn_grid_encode_fwd");
+        }
+    }
     switch (C) {
         case 1: hipLaunchKernelGGL((grid_fwd_kernel<T, D, 1>), grid, block, 0, st, inputs, emb, offsets, out, B, L, S, H, cg, dy_dx, gridtype, ac, lv); break;
         case 2: hipLaunchKernelGGL((grid_fwd_kernel<T, D, 2>), grid, block, 0, st, inputs, emb, offsets, out, B, L, S, H, cg, dy_dx, gridtype, ac, lv); break;
