@@ -537,6 +537,8 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
             t.record_stream(main)               # allocated on the side stream, consumed on the main stream
         return out, done
 
+    # (Issuing the next front half only behind this frame's MLP was measured: mlp_kernel 16.2 -> 15.8 ms without the ray caster
+    # beside its start, but the frame 22.4 -> 22.8 ms, because the ray caster then lands in the CNN phase too.)
     nxt = front(poses[0], 0)
     for i, pose in enumerate(poses):
         cur, done = nxt
