@@ -97,7 +97,7 @@ struct EncParams {
     const float *raydirs;      // [R, 3]
     const uint8_t *lut;        // [1024] minecraft id -> reduced label (ignore already mapped to dirt)
     const float *table3;       // [16][T][8] collapsed table
-    float *feat;               // [n_tiles][nch][8][64][8]
+    float *feat;               // [n_tiles][nch][8 k-steps][64 lanes][8 f16 hi | 8 f16 lo]: the MLP's B fragments, split
     float *dist;               // [n_tiles][nch][32]  new_dists * dists_scale (0 for padding samples)
     uint8_t *label;            // [n_tiles][nch][32]
     uint8_t *rayflag;          // [R] bit0 sky_only, bit1 nosky
@@ -299,6 +299,34 @@ __global__ __launch_bounds__(256) void pack_mx_kernel(const PackMxParams p) {
     }
 }
 
+// f32 -> (hi, lo) f16 pair with hi + lo == x to ~2^-22 relative.  hi is rounded to NEAREST (v_cvt_pk_f16_f32, two
+// values per instruction, new in gfx950): for the full 3-term product the rounding mode of hi is irrelevant (lo
+// absorbs the remainder), but a layer evaluated WITHOUT the Whi.Xlo term (TERMS == 2 below) sees |x - hi| as its error:
+// half as large and unbiased with round-to-nearest (tools/precision_study.py: 2.2x less output error than with
+// v_cvt_pkrtz).  x - float(hi) is a single v_fma_mix_f32 reading the f16 half directly.
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ fp16x2 cvt_rtn(float a, float b) {
+    return __builtin_bit_cast(fp16x2, __builtin_convertvector(float2v{a, b}, half2v));
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], half8 &hi, half8 &lo) {
+    unsigned int hw[4], lw[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const fp16x2 hp = cvt_rtn(v[e], v[e + 1]);
+        const fp16x2 lp = cvt_rtn(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
+        hw[e / 2] = __builtin_bit_cast(unsigned int, hp);
+        lw[e / 2] = __builtin_bit_cast(unsigned int, lp);
+    }
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h4 = {hw[0], hw[1], hw[2], hw[3]}, l4 = {lw[0], lw[1], lw[2], lw[3]};
+    hi = __builtin_bit_cast(half8, h4);
+    lo = __builtin_bit_cast(half8, l4);
+}
+
 // =====================================================================================================
 // encode: sample placement + collapsed hash-grid lookup
 // =====================================================================================================
@@ -481,11 +509,17 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
                 }
             }
             float *o = fout + (size_t)s * 64 * 8;
-            // streaming stores: the 4.9 GB of features are written once and read once by the MLP kernel; they should not
+            // The features leave as the MLP's operands: the 8 values of this lane's B fragment split into f16 hi (first
+            // 16 bytes) and f16 lo (second 16 bytes) -- the same 32 bytes per lane and k-step as 8 floats, and exactly the
+            // split mlp_kernel used to do at every pass start (128 VALU instructions of a wave that has no issue slots to
+            // spare; this kernel waits for gathers anyway).
+            // Streaming stores: the 4.9 GB of features are written once and read once by the MLP kernel; they should not
             // displace the collapsed table (the gathers' working set) from L2 / Infinity Cache
-            typedef float f4v __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(f4v{res[0], res[1], res[2], res[3]}, reinterpret_cast<f4v *>(o));
-            __builtin_nontemporal_store(f4v{res[4], res[5], res[6], res[7]}, reinterpret_cast<f4v *>(o + 4));
+            half8 hi8, lo8;
+            split8(res, hi8, lo8);
+            typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(__builtin_bit_cast(u4v, hi8), reinterpret_cast<u4v *>(o));
+            __builtin_nontemporal_store(__builtin_bit_cast(u4v, lo8), reinterpret_cast<u4v *>(o + 4));
         }
     }
     // per-ray flags: any over the ray's 4 lanes
@@ -590,34 +624,6 @@ __device__ __forceinline__ f32x16 zero16() {
 #pragma unroll
     for (int r = 0; r < 16; r++) z[r] = 0.f;
     return z;
-}
-
-// f32 -> (hi, lo) f16 pair with hi + lo == x to ~2^-22 relative.  hi is rounded to NEAREST (v_cvt_pk_f16_f32, two
-// values per instruction, new in gfx950): for the full 3-term product the rounding mode of hi is irrelevant (lo
-// absorbs the remainder), but a layer evaluated WITHOUT the Whi.Xlo term (TERMS == 2 below) sees |x - hi| as its error:
-// half as large and unbiased with round-to-nearest (tools/precision_study.py: 2.2x less output error than with
-// v_cvt_pkrtz).  x - float(hi) is a single v_fma_mix_f32 reading the f16 half directly.
-typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float float2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ fp16x2 cvt_rtn(float a, float b) {
-    return __builtin_bit_cast(fp16x2, __builtin_convertvector(float2v{a, b}, half2v));
-}
-
-__device__ __forceinline__ void split8(const float (&v)[8], half8 &hi, half8 &lo) {
-    unsigned int hw[4], lw[4];
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const fp16x2 hp = cvt_rtn(v[e], v[e + 1]);
-        const fp16x2 lp = cvt_rtn(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
-        hw[e / 2] = __builtin_bit_cast(unsigned int, hp);
-        lw[e / 2] = __builtin_bit_cast(unsigned int, lp);
-    }
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 h4 = {hw[0], hw[1], hw[2], hw[3]}, l4 = {lw[0], lw[1], lw[2], lw[3]};
-    hi = __builtin_bit_cast(half8, h4);
-    lo = __builtin_bit_cast(half8, l4);
 }
 
 struct Ring {
@@ -1426,7 +1432,14 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     for (int e = 0; e < 8; e++) raw[s][e] = t[2 * s + (e >> 2)][e & 3];
             }
 #pragma unroll
-            for (int s = 0; s < 8; s++) split8(raw[s], bh[s], bl[s]);
+            for (int s = 0; s < 8; s++) {   // encode_kernel wrote the fragment already split: dwords 0..3 = f16 hi, 4..7 = f16 lo
+                const u32x4v hw = {__builtin_bit_cast(unsigned int, raw[s][0]), __builtin_bit_cast(unsigned int, raw[s][1]),
+                                   __builtin_bit_cast(unsigned int, raw[s][2]), __builtin_bit_cast(unsigned int, raw[s][3])};
+                const u32x4v lw = {__builtin_bit_cast(unsigned int, raw[s][4]), __builtin_bit_cast(unsigned int, raw[s][5]),
+                                   __builtin_bit_cast(unsigned int, raw[s][6]), __builtin_bit_cast(unsigned int, raw[s][7])};
+                bh[s] = __builtin_bit_cast(half8, hw);
+                bl[s] = __builtin_bit_cast(half8, lw);
+            }
             if constexpr (DBG & 128) {
                 asm volatile("s_waitcnt vmcnt(0)" ::"v"(bh[7]), "v"(bl[7]) : "memory");
                 t_stage += __builtin_readcyclecounter() - t_in0;

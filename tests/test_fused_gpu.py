@@ -89,7 +89,9 @@ def test_encode_matches_oracle(renderer, oracle, weights_full, lut, tag):
                                g["cam_ori"][None], g["z"], g["global_enc"], ns, sky_avg=g["sky_avg"], return_aux=True)
     nch = (ns + 3) // 4
     ntile = (R + 7) // 8
-    feat = buf["feat"].cpu().numpy().reshape(ntile, nch, 8, 64, 8)
+    # the features are stored as the MLP's operands: per lane and k-step 8 f16 hi + 8 f16 lo (hi + lo = the value to 2^-22)
+    fh = buf["feat"].cpu().numpy().view(np.float16).reshape(ntile, nch, 8, 64, 2, 8).astype(np.float32)
+    feat = fh[..., 0, :] + fh[..., 1, :]
     dist = buf["dist"].cpu().numpy().reshape(ntile, nch, 32)
     label = buf["label"].cpu().numpy().reshape(ntile, nch, 32)
     # un-permute: lane = h*32 + 4*ray_in_tile + sample_in_step ; level = 2*s + h
