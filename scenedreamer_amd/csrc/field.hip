@@ -635,25 +635,47 @@ struct Ring {
     int lane;
     int voff;             // per-lane byte offset of this wave's first piece inside a slot: wave*4096 + lane*16
     unsigned lds_lane;    // LDS byte address of this lane's 16 B inside fragment 0 of ring position 0
+    int src_delta;        // (scalar) voff - lds_lane: what turns lds_lane into this lane's byte offset inside a slot
     int pend_global, pend_in_pass;   // slot whose refill was granted by the last ring_acquire (issued piecewise after it)
+    const char *pend_src;            // this lane's source address of that refill's first piece
 };
 
+// Per-lane source address of a slot's first DMA piece = uniform slot base + this lane's offset (wave * 8 KiB + lane * 16).
+// It is built HERE, per slot, by three VALU instructions inside one opaque asm block from the SGPR base and the lane's
+// LDS address (a register every unit needs anyway), instead of leaving the arithmetic to hipcc: hipcc re-associates it
+// into a kernel-long per-lane 64-bit base (wbytes + lane offset) plus a uniform slot offset -- two VGPRs for the whole
+// kernel, which the fp6 variant spilled to scratch and reloaded at every refill behind `s_waitcnt vmcnt(0)`: a full drain
+// of the DMA ring eleven times per pass in fc_5 alone (SQ_WAIT_ANY 11.5 % -> 17.6 % of the wave time).
+__device__ __forceinline__ const char *ring_lane_src(const char *slot_base, const Ring &r) {
+    unsigned int lo, hi;
+    const unsigned int b_lo = (unsigned int)(size_t)slot_base, b_hi = (unsigned int)((size_t)slot_base >> 32);
+    // lane offset = (lds_lane - lds_lane_base) + wave * PIECES * 1024, lds_lane_base + ... folded into `delta` (uniform)
+    asm volatile("v_add_u32 %0, %2, %3\n\t"
+                 "v_add_co_u32 %0, vcc, %4, %0\n\t"
+                 "v_mov_b32 %1, %5\n\t"
+                 "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(r.lds_lane), "s"(r.src_delta), "s"(b_lo), "s"(b_hi)
+                 : "vcc");
+    return reinterpret_cast<const char *>(((size_t)hi << 32) | lo);
+}
+
 template <int K>
-__device__ __forceinline__ void ring_dma(const char *sbase, char *dbase, const Ring &r) {
-    // address = uniform (SGPR) slot base + one per-lane VGPR offset + immediate; LDS destination is wave-uniform;
-    // the instruction offset is added to the global AND to the LDS address (LDS = M0 + offset + lane*16)
-    // (the immediate is a 13-bit signed field: 4096 and up would silently wrap to negative offsets)
-    __builtin_amdgcn_global_load_lds((glb_char *)(sbase + r.voff + (K / 4) * 4096), (lds_char *)(dbase + (K / 4) * 4096), 16,
-                                     (K % 4) * 1024, 0);
+__device__ __forceinline__ void ring_dma(const char *lane_src, char *dbase) {
+    // address = this lane's source address of the slot (+ 4 KiB for the second group of four pieces) + immediate; the LDS
+    // destination is wave-uniform; the instruction offset is added to the global AND to the LDS address
+    // (LDS = M0 + offset + lane*16).  (The immediate is a 13-bit signed field: 4096 and up would silently wrap to
+    // negative offsets.)
+    __builtin_amdgcn_global_load_lds((glb_char *)(lane_src + (K / 4) * 4096), (lds_char *)(dbase + (K / 4) * 4096), 16, (K % 4) * 1024, 0);
 }
 
 __device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_global, int slot_in_pass) {
     const int pos = slot_global & (NSLOT - 1);
-    const char *sbase = r.wbytes + (size_t)slot_in_pass * SLOT_BYTES;
+    const char *src = ring_lane_src(r.wbytes + (size_t)slot_in_pass * SLOT_BYTES, r);
     char *dbase = lds + LDS_RING + pos * SLOT_BYTES + r.wave * (PIECES * 1024);
-    ring_dma<0>(sbase, dbase, r); ring_dma<1>(sbase, dbase, r); ring_dma<2>(sbase, dbase, r); ring_dma<3>(sbase, dbase, r);
+    ring_dma<0>(src, dbase); ring_dma<1>(src, dbase); ring_dma<2>(src, dbase); ring_dma<3>(src, dbase);
     if constexpr (PIECES == 8) {
-        ring_dma<4>(sbase, dbase, r); ring_dma<5>(sbase, dbase, r); ring_dma<6>(sbase, dbase, r); ring_dma<7>(sbase, dbase, r);
+        ring_dma<4>(src, dbase); ring_dma<5>(src, dbase); ring_dma<6>(src, dbase); ring_dma<7>(src, dbase);
     }
 }
 
@@ -663,9 +685,8 @@ __device__ __forceinline__ void ring_issue(char *lds, const Ring &r, int slot_gl
 template <int K>
 __device__ __forceinline__ void ring_issue_piece(char *lds, const Ring &r) {
     const int pos = r.pend_global & (NSLOT - 1);
-    const char *sbase = r.wbytes + (size_t)r.pend_in_pass * SLOT_BYTES;
     char *dbase = lds + LDS_RING + pos * SLOT_BYTES + r.wave * (PIECES * 1024);
-    ring_dma<K>(sbase, dbase, r);
+    ring_dma<K>(r.pend_src, dbase);
 }
 
 // make slot r.g (and r.g+1) readable for everybody, free slot r.g-1 for its refill (ring_issue_piece<0..3>)
@@ -675,6 +696,7 @@ __device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
     if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
     r.pend_global = r.g + DMA_AHEAD;
     r.pend_in_pass = r.next_in_pass;
+    r.pend_src = ring_lane_src(r.wbytes + (size_t)r.next_in_pass * SLOT_BYTES, r);
     r.next_in_pass = r.next_in_pass + 1 == r.slots_per_pass ? 0 : r.next_in_pass + 1;
     const int pos = r.g & (NSLOT - 1);
     r.g++;
@@ -1316,6 +1338,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     r.lane = lane;
     r.voff = r.wave * (PIECES * 1024) + lane * 16;
     r.lds_lane = (unsigned)(size_t)(const lds_char *)(lds + LDS_RING) + lane * 16;
+    r.src_delta = r.wave * (PIECES * 1024) - (int)(unsigned)(size_t)(const lds_char *)(lds + LDS_RING);
 #pragma unroll
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
     r.next_in_pass = DMA_AHEAD;
@@ -1691,6 +1714,7 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
     r.lane = lane;
     r.voff = r.wave * (PIECES * 1024) + lane * 16;
     r.lds_lane = (unsigned)(size_t)(const lds_char *)(lds + LDS_RING) + lane * 16;
+    r.src_delta = r.wave * (PIECES * 1024) - (int)(unsigned)(size_t)(const lds_char *)(lds + LDS_RING);
 #pragma unroll
     for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
     r.next_in_pass = DMA_AHEAD;
