@@ -265,7 +265,7 @@ class Renderer:
                                                               feats, B, 5, 8, self.grid_L, self.grid_S, 16, False, dummy,
                                                               0, False))
                 achieved = B * 16916 / (ms * 1e-3) / 1e9
-                grid = {"bound": "hbm", "kernel": "grid_fwd_kernel<float,5,8>", "achieved": achieved,
+                grid = {"bound": "hbm", "kernel": "grid_fwd_quad_kernel<5,8> (drop-in GridEncoder.forward, 32-corner 5-D gather)", "achieved": achieved,
                         "peak": hbm_peak_gbps, "unit": "GB/s", "frac": achieved / hbm_peak_gbps, "traffic": None,
                         "samples_per_launch": B, "algorithmic_bytes_per_sample": 16916, "avg_launch_ms": ms}
                 return grid, grid
