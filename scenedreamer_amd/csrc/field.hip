@@ -16,10 +16,13 @@
 //   pack_kernel       once per style code.  Folded MLP weights (W * alpha) are split into f16 hi + f16 lo
 //                     and laid out in MFMA A-fragment order, so a wave fetches one fragment as one
 //                     fully coalesced 1 KiB access and no shuffles are needed anywhere.
+//   pack_mx_kernel    the colour layers' part of that stream as f16 hi fragments + block-scaled fp6 fragments
+//                     of Wlo and Whi (layer8x).
 //   encode_kernel     per frame, one wave per 8 rays, 4 samples of every ray per step (32 MFMA columns):
 //                     places the samples (bit-identical decisions to the reference), blends the 16
-//                     levels from the collapsed table and writes the features directly in the MLP's
-//                     B-fragment order.  Pure gather: bound by L2 / Infinity-Cache / HBM bandwidth.
+//                     levels from the collapsed table and writes the features as the MLP's B fragments,
+//                     already split into f16 hi / lo.  Reads the frame-wide ray arrays through a ray window.
+//                     Pure gather: bound by L2 / Infinity-Cache / HBM bandwidth.
 //   mlp_kernel        per frame, persistent, one wave per SIMD (4 per CU), 32 samples per wave step.
 //                     The MLP is evaluated TRANSPOSED: D^T[feature][sample] = W[feature][k] * X[k][sample],
 //                     weights are the MFMA A operand, samples the B operand.  A wave keeps all 256
@@ -30,9 +33,13 @@
 //                     amplifies hidden-activation error by ~1e2, which plain f16/bf16 MFMA misses by 10x
 //                     (measured).  Every product is therefore evaluated as a 3-term split
 //                     (Whi*Xhi + Wlo*Xhi + Whi*Xlo, f32 accumulate): ~2^-21 relative error at 3 f16 MFMAs
-//                     per tile, 5.3x the rate of the f32 MFMA.
+//                     per tile, 5.3x the rate of the f32 MFMA.  In the colour layers fc_5 / fc_6, whose error
+//                     nothing amplifies, the two correction terms run as block-scaled fp6 products
+//                     (v_mfma_scale_f32_32x32x64_f8f6f4: K = 64 at the issue cost of a K = 16 f16 MFMA).
 //                     Volume rendering, the density head, label bias, clamp and sky blend run in the
-//                     epilogues on the VALU.
+//                     epilogues on the VALU.  The persistent workgroups draw their 32-ray groups from a
+//                     ticket counter; groups whose rays all miss are skipped.
+//   sky_kernel        the same machinery for SKYMLP on every ray of the padded frame + the frame mean.
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
