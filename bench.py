@@ -281,6 +281,7 @@ def main():
         R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=other)
     torch.cuda.synchronize()
     other_ms = 1000.0 * (time.perf_counter() - t1) / n_other if n_other else None
+    roof_cnn = None
     if tile_parallel:     # per-kernel records on this rank's band (every rank does 1/N of the frame)
         roof, roof_grid = None, None
     elif probe.get("mlp_kernel") and fused_eps(R) == 0.0:
@@ -294,6 +295,17 @@ def main():
             timing=f"HIP events around each of the {len(probe['mlp_kernel'])} launches of the timed region, on the launch stream "
                    "(mlp_kernel: main; encode_kernel: side stream, where it shares the GPU with the previous frame's "
                    "mlp_kernel / conv_kernel -- its stand-alone duration is `standalone_ms`)")
+        # render CNN (5 015 040 FLOP per pixel of the evaluated frame): its seven launches share the GPU with the
+        # next frame's sky MLP / sample encode on the side stream in the timed region; `stage_ms.cnn` is the same CNN alone
+        px = (hw[0] + 8) * (hw[1] + 8) if args.apron == "minimal" else (hw[0] + 30) * (hw[1] + 30)
+        ms_cnn = ms_of("render_cnn")
+        roof_cnn = {"bound": "mfma", "kernel": "conv_kernel<1|9> x 7 (RenderCNN; 1x1 layers 3-term f16, 3x3 layers one f16 product)",
+                    "pixels": px, "algorithmic_flop_per_pixel": 5015040, "avg_ms_in_timed_region": ms_cnn,
+                    "achieved": px * 5015040 / (ms_cnn * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                    "frac": px * 5015040 / (ms_cnn * 1e-3) / 1e12 / 2500.0,
+                    "alone_ms": stage_ms.get("cnn"),
+                    "frac_alone": (px * 5015040 / (stage_ms["cnn"] * 1e-3) / 1e12 / 2500.0) if stage_ms.get("cnn") else None,
+                    "timing": "HIP events around the CNN of every timed frame on the main stream"}
         if not args.profile:
             alone = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
             roof["standalone_ms"], roof_grid["standalone_ms"] = alone[0]["avg_launch_ms"], alone[1]["avg_launch_ms"]
@@ -329,7 +341,7 @@ def main():
                                      "pixel -- the image is bit-identical (tests/test_render_gpu.py, test_fullsize_gpu.py)"},
             "frame_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "delivered_frames_per_s_uint8_host": delivered_fps,
             "stage_ms": stage_ms, "setup_s": setup_s, "broadcast": bstats or None, f"ms_per_step_apron_{other}": other_ms,
-            "roofline": roof, "roofline_grid_sampler": roof_grid,
+            "roofline": roof, "roofline_grid_sampler": roof_grid, "roofline_cnn": roof_cnn,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, weights, scene, R.z.cpu().numpy(), R.global_enc.cpu().numpy())

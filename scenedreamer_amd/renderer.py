@@ -559,7 +559,13 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
             if getattr(self, "_mfma_cnn", None) is None:
                 from .cnn import MfmaCNN
                 self._mfma_cnn = MfmaCNN(self, getattr(self, "cnn_terms3x3", None))
+            if probe is not None:
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record(main)
             img = self._mfma_cnn(net_out)
+            if probe is not None:
+                c1.record(main)
+                probe.setdefault("render_cnn", []).append((c0, c1))
             c = crop - o
             yield img[:, :, c:-c, c:-c] if c else img
 
