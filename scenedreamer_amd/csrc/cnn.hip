@@ -69,6 +69,7 @@ struct ConvParams {
     float *img;                // [3][H*W]
     int H, W, Hb, Wb;          // frame and padded-buffer extent (buffer pixel (y,x) -> (y+1, x+1))
     long chunk_bytes;          // Hb*Wb*32: byte stride between channel chunks of a plane
+    unsigned row_inc, chunk_inc;   // 3x3 k-order increments of the activation offset: tap (r,2) -> (r+1,0), tap (2,2) -> (0,0) of the next chunk
     int gx, gy, n_groups;      // workgroup patches (16 x 16 pixels)
 };
 
@@ -89,49 +90,70 @@ __device__ __forceinline__ half2v cvt_rtn(float a, float b) {
     return __builtin_convertvector(float2v{a, b}, half2v);
 }
 
-// DMA of k-step `kt` of a pass into ring position `pos`
-// one of the 4 DMA pieces a wave contributes to ring position `pos` for k-step `kt`: 0, 1 = its 2 KiB of the weight
-// fragments, 2 / 3 = its own activation fragments (hi / lo plane)
+// ---- the DMA stream ----------------------------------------------------------------------------------------------------
+// k order is channel-chunk major: k = 9*s + tap.  The 9 taps of one 16-channel chunk re-read the same (patch + halo) x 32 B
+// region, which stays in L1/L2; with tap-major order every tap re-streamed the whole patch from the Infinity Cache (measured
+// 3.2 GB fetched per launch for 0.58 GB of input).
+// The stream's position is kept INCREMENTALLY in scalar registers (a byte offset inside a plane, measured from tap (0,0) of
+// chunk 0, a tap counter and the ring-slot index of the weights): the first version recomputed k / 9, k % 9, tap / 3 and a
+// 64-bit multiply-add per activation piece, ~30 scalar + 6 vector instructions each, as many issue slots as the slot's MFMAs.
+// Every DMA's address is (scalar base) + (32-bit per-lane offset), the saddr form of global_load_lds: no vector address arithmetic.
+struct Stream {
+    unsigned long off;   // activation byte offset of the current k-step
+    int tap;             // 0..8 (3x3 only)
+    int w;               // ring slot inside the patch (weights)
+};
+
 template <int TAPS>
-__device__ __forceinline__ long tap_offset(const ConvParams &p, int k) {
-    // k order is channel-chunk major: k = 9*s + tap.  The 9 taps of one 16-channel chunk re-read the same
-    // (patch + halo) x 32 B region, which stays in L1/L2; with tap-major order every tap re-streamed the whole
-    // patch from the Infinity Cache (measured 3.2 GB fetched per launch for 0.58 GB of input).
+__device__ __forceinline__ void stream_advance_k(const ConvParams &p, Stream &st) {
     if constexpr (TAPS == 9) {
-        const int s = k / 9, tap = k - 9 * s;
-        return ((long)(tap / 3 - 1) * p.Wb + (tap % 3 - 1)) * 32 + (long)s * p.chunk_bytes;
+        unsigned inc = ((0x24u >> st.tap) & 1u) ? p.row_inc : 32u;   // taps 2 and 5 end a row
+        inc = st.tap == 8 ? p.chunk_inc : inc;
+        st.off += inc;
+        st.tap = st.tap == 8 ? 0 : st.tap + 1;
     } else {
-        return (long)k * p.chunk_bytes;   // 1x1: k-step = channel chunk
+        st.off += (unsigned long)p.chunk_bytes;   // 1x1: k-step = channel chunk
     }
 }
 
-template <int TAPS, int TERMS, int PIECE>
-__device__ __forceinline__ void issue_piece(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
-    if constexpr (PIECE < 2) {
-        // (the instruction offset applies to the global AND the LDS address)
-        const char *wsrc = p.wpk + (size_t)kt * A_BYTES + wave * 2048 + lane * 16;
-        char *wdst = lds + pos * SLOT_BYTES + wave * 2048;
-        if constexpr (PIECE == 0) __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((glb_char *)wsrc, (lds_char *)wdst, 16, 1024, 0);
-    } else {
-        char *bdst = lds + pos * SLOT_BYTES + A_BYTES + wave * B_BYTES;
-        if constexpr (TERMS == 3) {   // hi and lo plane of k-step kt
-            const long toff = tap_offset<TAPS>(p, kt);
-            if constexpr (PIECE == 2) __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + toff), (lds_char *)bdst, 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xl + boff + toff), (lds_char *)(bdst + 1024), 16, 0, 0);
-        } else {                      // hi plane of k-steps 2 kt and 2 kt + 1
-            if constexpr (PIECE == 2) __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + tap_offset<TAPS>(p, 2 * kt)), (lds_char *)bdst, 16, 0, 0);
-            else __builtin_amdgcn_global_load_lds((glb_char *)((const char *)p.xh + boff + tap_offset<TAPS>(p, 2 * kt + 1)), (lds_char *)(bdst + 1024), 16, 0, 0);
-        }
-    }
-}
+// scalar operands of the 4 DMA pieces a wave contributes to one ring slot: 0, 1 = its 2 KiB of the weight fragments,
+// 2 / 3 = its own activation fragments (TERMS == 3: hi / lo plane of one k-step; TERMS == 1: hi plane of two k-steps)
+struct SlotIssue {
+    const char *w;        // weights of the slot + this wave's 2 KiB
+    const char *a0, *a1;  // plane base + k-step offset of piece 2 / 3
+    unsigned voff;        // per-lane activation offset (this patch's or the next one's)
+    char *dst;            // ring position
+};
 
 template <int TAPS, int TERMS>
-__device__ __forceinline__ void issue_slot(char *lds, const ConvParams &p, int pos, int kt, int wave, int lane, long boff) {
-    issue_piece<TAPS, TERMS, 0>(lds, p, pos, kt, wave, lane, boff);
-    issue_piece<TAPS, TERMS, 1>(lds, p, pos, kt, wave, lane, boff);
-    issue_piece<TAPS, TERMS, 2>(lds, p, pos, kt, wave, lane, boff);
-    issue_piece<TAPS, TERMS, 3>(lds, p, pos, kt, wave, lane, boff);
+__device__ __forceinline__ SlotIssue stream_next_slot(const ConvParams &p, Stream &st, char *lds, int pos, int wave, unsigned voff, int ksteps) {
+    SlotIssue si;
+    si.w = p.wpk + (size_t)st.w * A_BYTES + wave * 2048;
+    si.a0 = (const char *)p.xh + st.off;
+    if constexpr (TERMS == 1) {
+        stream_advance_k<TAPS>(p, st);
+        si.a1 = (const char *)p.xh + st.off;
+    } else {
+        si.a1 = (const char *)p.xl + st.off;
+    }
+    stream_advance_k<TAPS>(p, st);
+    st.w++;
+    if (st.w == ksteps) {   // the stream runs on into the next patch
+        st.w = 0;
+        st.off = 0;
+    }
+    si.voff = voff;
+    si.dst = lds + pos * SLOT_BYTES;
+    return si;
+}
+
+template <int PIECE>
+__device__ __forceinline__ void issue_piece(const SlotIssue &si, int wave, int lane) {
+    // (the instruction offset applies to the global AND the LDS address)
+    if constexpr (PIECE == 0) __builtin_amdgcn_global_load_lds((glb_char *)(si.w + (unsigned)(lane * 16)), (lds_char *)(si.dst + wave * 2048), 16, 0, 0);
+    if constexpr (PIECE == 1) __builtin_amdgcn_global_load_lds((glb_char *)(si.w + (unsigned)(lane * 16)), (lds_char *)(si.dst + wave * 2048), 16, 1024, 0);
+    if constexpr (PIECE == 2) __builtin_amdgcn_global_load_lds((glb_char *)(si.a0 + si.voff), (lds_char *)(si.dst + A_BYTES + wave * B_BYTES), 16, 0, 0);
+    if constexpr (PIECE == 3) __builtin_amdgcn_global_load_lds((glb_char *)(si.a1 + si.voff), (lds_char *)(si.dst + A_BYTES + wave * B_BYTES + 1024), 16, 0, 0);
 }
 
 // Fragment reads are inline asm with hand-counted s_waitcnt: behind a pending LDS-DMA the compiler's own wait
@@ -166,19 +188,18 @@ __device__ __forceinline__ void lds_wait() {
 // reads are the last LDS operations of a unit: "lgkmcnt(reads of the previous unit)" at the start of a unit means
 // this unit's fragments have landed.
 template <int TAPS, int TERMS, int DBG, int U>
-__device__ __forceinline__ void conv_unit(char *lds, const ConvParams &p, f32x16 (&acc)[8], half8 (&a)[4][4], half8 (&bcur)[2],
-                                          half8 (&bnext)[2], unsigned slot, unsigned slot_n, unsigned b_off, int pos_issue,
-                                          int kt_issue, long boff_issue, int wave, int lane) {
+__device__ __forceinline__ void conv_unit(f32x16 (&acc)[8], half8 (&a)[4][4], half8 (&bcur)[2], half8 (&bnext)[2], unsigned slot,
+                                          unsigned slot_n, unsigned b_off, const SlotIssue &si, int wave, int lane) {
     constexpr int ib = 2 * U;
     half8(&au)[4] = a[U];
     half8(&nx)[4] = a[(U + 2) & 3];
     const unsigned src = U < 2 ? slot : slot_n;            // unit U+2 of this slot, or unit U-2 of the next one
     constexpr int OFF = ((U + 2) & 3) * 4096;
-    lds_wait<U == 3 ? 6 : 4>();
+    if constexpr (!(DBG & 64)) lds_wait<U == 3 ? 6 : 4>();
 #define SDN_GAP(K) \
-    if constexpr (K == 0 && !(DBG & 1)) issue_piece<TAPS, TERMS, U>(lds, p, pos_issue, kt_issue, wave, lane, boff_issue); \
-    if constexpr (K == 0 && U == 2) { ds_read16<0>(bnext[0], slot_n + b_off); ds_read16<1024>(bnext[1], slot_n + b_off); } \
-    if constexpr (K >= 1 && K <= 4) ds_read16<OFF + (K - 1) * 1024>(nx[K - 1], src); \
+    if constexpr (K == 0 && !(DBG & 1)) issue_piece<U>(si, wave, lane); \
+    if constexpr (K == 0 && U == 2 && !(DBG & 64)) { ds_read16<0>(bnext[0], slot_n + b_off); ds_read16<1024>(bnext[1], slot_n + b_off); } \
+    if constexpr (K >= 1 && K <= 4 && !(DBG & 64)) ds_read16<OFF + (K - 1) * 1024>(nx[K - 1], src); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DBG & 16) {
         asm volatile("" ::"v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]), "v"(bcur[0]), "v"(bcur[1]));
@@ -229,19 +250,27 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
 
     int grp = blockIdx.x;
     if (grp >= p.n_groups) return;
+    // per-lane byte offset of the lane's pixel inside chunk 0, measured from the first tap of the k order (3x3: the pixel
+    // one row up and one column left; the zero border makes that address valid for every pixel of the frame)
+    const unsigned tap0 = TAPS == 9 ? (unsigned)(p.Wb + 1) * 32u : 0u;
     int py, px;
-    long boff = lane_pixel_offset(p, grp, wave, lane, py, px);
+    unsigned voff = (unsigned)lane_pixel_offset(p, grp, wave, lane, py, px) - tap0;
     int grp_n = grp + gridDim.x;
     int pyn, pxn;
-    long boff_n = grp_n < p.n_groups ? lane_pixel_offset(p, grp_n, wave, lane, pyn, pxn) : boff;
+    unsigned voff_n = grp_n < p.n_groups ? (unsigned)lane_pixel_offset(p, grp_n, wave, lane, pyn, pxn) - tap0 : voff;
 
+    const int ksteps = p.ksteps;
+    Stream st{0ul, 0, 0};
     int pos_issue = 0, pos_use = 0;
 #pragma unroll
     for (int q = 0; q < AHEAD; q++) {
-        issue_slot<TAPS, TERMS>(lds, p, pos_issue, q, wave, lane, boff);
+        const SlotIssue si = stream_next_slot<TAPS, TERMS>(p, st, lds, pos_issue, wave, voff, ksteps);
+        issue_piece<0>(si, wave, lane);
+        issue_piece<1>(si, wave, lane);
+        issue_piece<2>(si, wave, lane);
+        issue_piece<3>(si, wave, lane);
         pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
     }
-    const int ksteps = p.ksteps;
 
     // Fragment registers: the weight fragments of 4 units (the unit in use, the next one, the one being read) and two
     // sets of this wave's activation fragments (k-steps alternate between them: the loop is unrolled by two so that
@@ -265,14 +294,13 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                 const int kt = kt2 + par;
                 // this k-step's bookkeeping first: it then runs while the wave would wait for the others at the barrier
                 // (behind the barrier it is ~20 scalar instructions of dead matrix time per k-step for every wave)
-                const int qn = kt + AHEAD;   // k-step to fetch during this one, possibly of the next patch
-                const int kt_issue = qn < ksteps ? qn : qn - ksteps;
-                const long boff_issue = qn < ksteps ? boff : boff_n;
-                const int pos_i = pos_issue;
+                // the slot fetched during this one: AHEAD slots on, possibly of the next patch
+                const SlotIssue si = stream_next_slot<TAPS, TERMS>(p, st, lds, pos_issue, wave, kt + AHEAD < ksteps ? voff : voff_n, ksteps);
                 pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
                 const unsigned slot = lds_lane + pos_use * SLOT_BYTES;
                 pos_use = pos_use + 1 == NSLOT ? 0 : pos_use + 1;
                 const unsigned slot_n = lds_lane + pos_use * SLOT_BYTES;
+                asm volatile("" ::"s"(si.w), "s"(si.a0), "s"(si.a1), "v"(si.voff), "v"(slot), "v"(slot_n));   // ... computed HERE
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free ---
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
@@ -285,10 +313,10 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                     lds_unit<1>(slot, a[1]);
                     primed = true;
                 }
-                conv_unit<TAPS, TERMS, DBG, 0>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
-                conv_unit<TAPS, TERMS, DBG, 1>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
-                conv_unit<TAPS, TERMS, DBG, 2>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
-                conv_unit<TAPS, TERMS, DBG, 3>(lds, p, acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, pos_i, kt_issue, boff_issue, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 0>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 1>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 2>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 3>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane);
             }
         }
         // the prefetches of the (possibly non-existent) next patch's first units must land before registers are reused
@@ -378,11 +406,11 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
         // ---- next patch ---------------------------------------------------------------------------------------------
         grp = grp_n;
         if (grp >= p.n_groups) break;
-        boff = boff_n;
+        voff = voff_n;
         py = pyn;
         px = pxn;
         grp_n = grp + gridDim.x;
-        boff_n = grp_n < p.n_groups ? lane_pixel_offset(p, grp_n, wave, lane, pyn, pxn) : boff;
+        voff_n = grp_n < p.n_groups ? (unsigned)lane_pixel_offset(p, grp_n, wave, lane, pyn, pxn) - tap0 : voff;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -515,6 +543,9 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms,
     p.H = H; p.W = W;
     sdn_conv_plane_dims(H, W, &p.Hb, &p.Wb);
     p.chunk_bytes = (long)p.Hb * p.Wb * 32;
+    SDN_REQUIRE(p.chunk_bytes < (1l << 32), "sdn_conv: frame too large (a channel chunk of a plane must stay below 4 GiB)");
+    p.row_inc = (unsigned)(p.Wb - 2) * 32u;
+    p.chunk_inc = (unsigned)(p.chunk_bytes - 2l * (p.Wb + 1) * 32);
     p.gx = sdn::div_up(W, PATCH_W);
     p.gy = sdn::div_up(H, PATCH_H);
     p.n_groups = p.gx * p.gy;
@@ -525,6 +556,19 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms,
         return sdn::check_launch("sdn_conv");
     }
     if (terms == 1) {
+#ifdef SDN_MLP_ABLATION
+        const char *e1 = getenv("SDN_CONV_DBG");   // timing experiments only (re-read per call); results are wrong unless 0
+        switch (e1 ? atoi(e1) : 0) {
+            case 1: hipLaunchKernelGGL((conv_kernel<9, 1, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 2: hipLaunchKernelGGL((conv_kernel<9, 2, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 16: hipLaunchKernelGGL((conv_kernel<9, 16, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 17: hipLaunchKernelGGL((conv_kernel<9, 17, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 19: hipLaunchKernelGGL((conv_kernel<9, 19, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 64: hipLaunchKernelGGL((conv_kernel<9, 64, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            default: hipLaunchKernelGGL((conv_kernel<9, 0, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+        }
+        return sdn::check_launch("sdn_conv");
+#endif
         hipLaunchKernelGGL((conv_kernel<9, 0, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
         return sdn::check_launch("sdn_conv");
     }
