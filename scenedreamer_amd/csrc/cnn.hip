@@ -147,6 +147,41 @@ __device__ __forceinline__ SlotIssue stream_next_slot(const ConvParams &p, Strea
     return si;
 }
 
+// The same, a quarter at a time: the main loop computes the operands of the NEXT slot's pieces in the shadow of this slot's
+// MFMAs (chunk U in unit U).  As one block at the top of a slot these ~45 scalar instructions were matrix-pipe idle time:
+// both waves of a SIMD run in lockstep behind the per-slot barrier, so neither had MFMAs in flight meanwhile.
+// The empty asm statements pin a chunk to its gap (inputs not earlier, outputs not later).
+template <int TAPS, int TERMS, int U>
+__device__ __forceinline__ void stream_chunk(const ConvParams &p, Stream &st, SlotIssue &sn, char *lds, int &pos, int wave,
+                                             unsigned voff_sel, int ksteps) {
+    if constexpr (U == 0) {
+        asm volatile("" : "+s"(st.w));
+        sn.w = p.wpk + (size_t)st.w * A_BYTES + wave * 2048;
+        sn.dst = lds + pos * SLOT_BYTES;
+        pos = pos + 1 == NSLOT ? 0 : pos + 1;
+        asm volatile("" ::"s"(sn.w), "s"(pos));
+    } else if constexpr (U == 1) {
+        asm volatile("" : "+s"(st.tap));
+        sn.a0 = (const char *)p.xh + st.off;
+        if constexpr (TERMS == 1) stream_advance_k<TAPS>(p, st);
+        asm volatile("" ::"s"(sn.a0), "s"(st.off), "s"(st.tap));
+    } else if constexpr (U == 2) {
+        asm volatile("" : "+s"(st.tap));
+        sn.a1 = (const char *)(TERMS == 1 ? p.xh : p.xl) + st.off;
+        stream_advance_k<TAPS>(p, st);
+        asm volatile("" ::"s"(sn.a1), "s"(st.off), "s"(st.tap));
+    } else {
+        asm volatile("" : "+s"(st.w));
+        st.w++;
+        if (st.w == ksteps) {   // the stream runs on into the next patch
+            st.w = 0;
+            st.off = 0;
+        }
+        sn.voff = voff_sel;
+        asm volatile("" ::"s"(st.w), "s"(st.off), "v"(sn.voff));
+    }
+}
+
 template <int PIECE>
 __device__ __forceinline__ void issue_piece(const SlotIssue &si, int wave, int lane) {
     // (the instruction offset applies to the global AND the LDS address)
@@ -189,7 +224,8 @@ __device__ __forceinline__ void lds_wait() {
 // this unit's fragments have landed.
 template <int TAPS, int TERMS, int DBG, int U>
 __device__ __forceinline__ void conv_unit(f32x16 (&acc)[8], half8 (&a)[4][4], half8 (&bcur)[2], half8 (&bnext)[2], unsigned slot,
-                                          unsigned slot_n, unsigned b_off, const SlotIssue &si, int wave, int lane) {
+                                          unsigned slot_n, unsigned b_off, const SlotIssue &si, int wave, int lane,
+                                          const ConvParams &p, Stream &st, SlotIssue &sn, char *lds, int &pos_issue, unsigned voff_sel, int ksteps) {
     constexpr int ib = 2 * U;
     half8(&au)[4] = a[U];
     half8(&nx)[4] = a[(U + 2) & 3];
@@ -200,6 +236,7 @@ __device__ __forceinline__ void conv_unit(f32x16 (&acc)[8], half8 (&a)[4][4], ha
     if constexpr (K == 0 && !(DBG & 1)) issue_piece<U>(si, wave, lane); \
     if constexpr (K == 0 && U == 2 && !(DBG & 64)) { ds_read16<0>(bnext[0], slot_n + b_off); ds_read16<1024>(bnext[1], slot_n + b_off); } \
     if constexpr (K >= 1 && K <= 4 && !(DBG & 64)) ds_read16<OFF + (K - 1) * 1024>(nx[K - 1], src); \
+    if constexpr (K == 2) stream_chunk<TAPS, TERMS, U>(p, st, sn, lds, pos_issue, wave, voff_sel, ksteps); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DBG & 16) {
         asm volatile("" ::"v"(au[0]), "v"(au[1]), "v"(au[2]), "v"(au[3]), "v"(bcur[0]), "v"(bcur[1]));
@@ -271,6 +308,9 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
         issue_piece<3>(si, wave, lane);
         pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
     }
+    // operands of the pieces issued during the first slot of the loop; from then on each slot prepares the next one's
+    SlotIssue si = stream_next_slot<TAPS, TERMS>(p, st, lds, pos_issue, wave, AHEAD < ksteps ? voff : voff_n, ksteps);
+    pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
 
     // Fragment registers: the weight fragments of 4 units (the unit in use, the next one, the one being read) and two
     // sets of this wave's activation fragments (k-steps alternate between them: the loop is unrolled by two so that
@@ -292,15 +332,13 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
 #pragma unroll
             for (int par = 0; par < 2; par++) {
                 const int kt = kt2 + par;
-                // this k-step's bookkeeping first: it then runs while the wave would wait for the others at the barrier
-                // (behind the barrier it is ~20 scalar instructions of dead matrix time per k-step for every wave)
-                // the slot fetched during this one: AHEAD slots on, possibly of the next patch
-                const SlotIssue si = stream_next_slot<TAPS, TERMS>(p, st, lds, pos_issue, wave, kt + AHEAD < ksteps ? voff : voff_n, ksteps);
-                pos_issue = pos_issue + 1 == NSLOT ? 0 : pos_issue + 1;
+                // `si`: the slot fetched during this one (AHEAD slots on, possibly of the next patch); `sn`: the one after it
+                SlotIssue sn;
+                const unsigned voff_sel = kt + 1 + AHEAD < ksteps ? voff : voff_n;
                 const unsigned slot = lds_lane + pos_use * SLOT_BYTES;
                 pos_use = pos_use + 1 == NSLOT ? 0 : pos_use + 1;
                 const unsigned slot_n = lds_lane + pos_use * SLOT_BYTES;
-                asm volatile("" ::"s"(si.w), "s"(si.a0), "s"(si.a1), "v"(si.voff), "v"(slot), "v"(slot_n));   // ... computed HERE
+                asm volatile("" ::"v"(voff_sel), "v"(slot), "v"(slot_n));   // ... computed HERE, before the barrier
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free ---
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
@@ -313,10 +351,11 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                     lds_unit<1>(slot, a[1]);
                     primed = true;
                 }
-                conv_unit<TAPS, TERMS, DBG, 0>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane);
-                conv_unit<TAPS, TERMS, DBG, 1>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane);
-                conv_unit<TAPS, TERMS, DBG, 2>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane);
-                conv_unit<TAPS, TERMS, DBG, 3>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane);
+                conv_unit<TAPS, TERMS, DBG, 0>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane, p, st, sn, lds, pos_issue, voff_sel, ksteps);
+                conv_unit<TAPS, TERMS, DBG, 1>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane, p, st, sn, lds, pos_issue, voff_sel, ksteps);
+                conv_unit<TAPS, TERMS, DBG, 2>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane, p, st, sn, lds, pos_issue, voff_sel, ksteps);
+                conv_unit<TAPS, TERMS, DBG, 3>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane, p, st, sn, lds, pos_issue, voff_sel, ksteps);
+                si = sn;
             }
         }
         // the prefetches of the (possibly non-existent) next patch's first units must land before registers are reused
@@ -564,6 +603,10 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms,
             case 16: hipLaunchKernelGGL((conv_kernel<9, 16, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
             case 17: hipLaunchKernelGGL((conv_kernel<9, 17, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
             case 19: hipLaunchKernelGGL((conv_kernel<9, 19, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 3: hipLaunchKernelGGL((conv_kernel<9, 3, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 65: hipLaunchKernelGGL((conv_kernel<9, 65, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 66: hipLaunchKernelGGL((conv_kernel<9, 66, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
+            case 67: hipLaunchKernelGGL((conv_kernel<9, 67, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
             case 64: hipLaunchKernelGGL((conv_kernel<9, 64, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
             default: hipLaunchKernelGGL((conv_kernel<9, 0, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
         }

@@ -18,7 +18,7 @@ x = torch.rand(1, H, W, 64, device=dev) * 2 - 1
 buf = cnn._buffers(H, W)
 cnn(x)
 for rep in range(2):
-    for dbg in (0, 1, 2, 4, 8, 12, 16, 17, 19, 64):
+    for dbg in (0, 1, 2, 3, 16, 17, 19, 64, 65, 66, 67):
         os.environ["SDN_CONV_DBG"] = str(dbg)
         t = _time_ms(lambda: cnn._conv(buf["a"], "conv2a", H, W, bias=R.w["denoiser.conv2a.bias"], dst=buf["b"]), 10)
         print(f"dbg {dbg:3d}: conv3x3 {t:.3f} ms", flush=True)
