@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """Timing ablations of the 1-term 3x3 convolution (build with SDN_MLP_ABLATION=1; results are wrong unless dbg = 0).
-bits: 1 no DMA in the loop, 2 no barrier, 4 weights always from slot 0, 8 activations always from one tap/chunk,
-16 no MFMA, 64 no fragment reads from LDS."""
+bits: 1 no DMA in the loop, 2 no barrier, 16 no MFMA, 64 no fragment reads from LDS (sums as listed in sdn_conv's switch)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
