@@ -278,7 +278,10 @@ __device__ __forceinline__ long lane_pixel_offset(const ConvParams &p, int grp, 
     return ((long)(py + 1) * p.Wb + (px + 1)) * 32 + h * 16;   // byte offset inside chunk 0
 }
 
-template <int TAPS, int DBG, int TERMS>
+// EPI: what the epilogue reads and writes besides (bias ->) LeakyReLU -> hi plane, known at compile time in the variants the
+// render CNN uses (straight-line code: the loads of several iterations overlap): 1 residual planes, 2 FiLM, 8 NO bias,
+// 16 lo plane too; 255 = anything, decided at run time from the pointers (incl. the fused projection, fp32 residual / output).
+template <int TAPS, int DBG, int TERMS, int EPI>
 __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[NSLOT * SLOT_BYTES];
     const int lane = threadIdx.x & 63;
@@ -319,7 +322,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
     half8 b[2][2];
     const unsigned lds_lane = lds_addr(lds) + lane * 16;
     const unsigned b_off = A_BYTES + wave * B_BYTES;
-    bool primed = false;
+    bool primed = false, first_patch = true;
 
     while (true) {
         f32x16 acc[8];
@@ -341,7 +344,10 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                 asm volatile("" ::"v"(voff_sel), "v"(slot), "v"(slot_n));   // ... computed HERE, before the barrier
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- acquire slot kt: mine of slots kt and kt+1 have landed, then everybody's; slot kt-1 is free ---
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
+                // (not in the first AHEAD - 1 slots behind an epilogue: those slots were drained in front of it, and its stores
+                // count in vmcnt too -- vector memory operations retire in order, so this wait would expose their whole write
+                // latency at the start of every patch; by slot AHEAD - 1 they have retired)
+                if (kt >= AHEAD - 1 || first_patch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
                 if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 if (!primed) {   // very first k-step of the kernel only
@@ -359,7 +365,9 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
             }
         }
         // the prefetches of the (possibly non-existent) next patch's first units must land before registers are reused
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (and the next patch's first AHEAD slots, all in flight by now, before the epilogue's stores are issued)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        first_patch = false;
 
         // ---- epilogue of this patch -----------------------------------------------------------------------------
         const bool in_frame = py < p.H && px < p.W;
@@ -371,31 +379,44 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
             // The packed weights permute the rows of every 32-channel block (pack_conv_kernel) so that accumulator
             // register r of half-wave h is channel 32*ib + 16*h + r: a lane owns one whole 16-channel chunk of its pixel
             // per row block = 32 contiguous bytes of each plane, and the 8 pixels of a tile row are 256 contiguous bytes.
+            //
+            // TWO passes over the accumulators.  Pass 1 loads (bias, residual, FiLM, projection rows) and leaves the activation
+            // in the accumulator registers; pass 2 converts and stores.  Vector memory operations retire in order, so in
+            // the one-pass form (load, compute, store per 8 channels) every iteration's wait for its loads was also a wait for
+            // the previous iteration's stores to be acknowledged: 16 exposed store round trips per patch, ~24 k cycles of a
+            // ~120 k-cycle patch of the 1-term 3x3 layers (cycle counters) and most of a 1x1 layer's time.
+            constexpr bool SPEC = EPI != 255;
+            const bool has_bias = SPEC ? !(EPI & 8) : p.bias != nullptr, has_rp = SPEC ? bool(EPI & 1) : p.rh != nullptr;
+            const bool has_mod = SPEC ? bool(EPI & 2) : p.mod_w != nullptr, has_r32 = !SPEC && p.resid;
+            const bool has_proj = !SPEC && p.proj_w, has_o32 = !SPEC && p.of32;
+            const bool has_oh = SPEC || p.oh, has_ol = SPEC ? bool(EPI & 16) : p.ol != nullptr;
+            int he = h;   // opaque per patch: otherwise the per-channel addresses below are hoisted out of the patch loop and
+            asm volatile("" : "+v"(he));   // their registers stay live across the main loop
 #pragma unroll
             for (int ib = 0; ib < 8; ib++) {
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
-                    const int c0 = 32 * ib + 16 * h + 8 * q;                 // 8 consecutive channels
+                    const int c0 = 32 * ib + 16 * he + 8 * q;                // 8 consecutive channels
+                    const long po = ((long)(2 * ib + he) * plane_px + ppix) * 16 + 8 * q;   // element offset inside a plane
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) v[e] = acc[ib][8 * q + e];
-                    if (p.bias) {
+                    if (has_bias) {
                         const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + c0), b1 = *reinterpret_cast<const float4 *>(p.bias + c0 + 4);
                         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                     }
-                    const long po = ((long)(2 * ib + h) * plane_px + ppix) * 16 + 8 * q;   // element offset inside a plane
-                    if (p.resid) {   // y = y + conv(...)   (gancraft_base.py:213, :216)
+                    if (has_r32) {   // y = y + conv(...)   (gancraft_base.py:213, :216)
                         const float4 r0 = *reinterpret_cast<const float4 *>(p.resid + orow * CH + c0);
                         const float4 r1 = *reinterpret_cast<const float4 *>(p.resid + orow * CH + c0 + 4);
                         v[0] = r0.x + v[0]; v[1] = r0.y + v[1]; v[2] = r0.z + v[2]; v[3] = r0.w + v[3];
                         v[4] = r1.x + v[4]; v[5] = r1.y + v[5]; v[6] = r1.z + v[6]; v[7] = r1.w + v[7];
-                    } else if (p.rh) {   // the same, y kept as hi + lo planes (exact to 2^-22; read before the in-place store)
+                    } else if (has_rp) {   // the same, y kept as hi + lo planes (exact to 2^-22; read before the in-place store)
                         const half8 h8 = *reinterpret_cast<const half8 *>(p.rh + po);
                         const half8 l8 = *reinterpret_cast<const half8 *>(p.rl + po);
 #pragma unroll
                         for (int e = 0; e < 8; e++) v[e] = ((float)h8[e] + (float)l8[e]) + v[e];
                     }
-                    if (p.mod_w) {   // modulate: x * (w + 1) + b   (:197-200)
+                    if (has_mod) {   // modulate: x * (w + 1) + b   (:197-200)
 #pragma unroll
                         for (int e4 = 0; e4 < 2; e4++) {
                             const float4 mw = *reinterpret_cast<const float4 *>(p.mod_w + c0 + 4 * e4);
@@ -406,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                     }
 #pragma unroll
                     for (int e = 0; e < 8; e++) v[e] = vmax(v[e], 0.2f * v[e]);   // LeakyReLU(0.2)
-                    if (p.proj_w) {   // conv4 (256 -> 3, 1x1): this lane's 8 channels of its pixel
+                    if (has_proj) {   // conv4 (256 -> 3, 1x1): this lane's 8 channels of its pixel
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
                             const float4 w0 = *reinterpret_cast<const float4 *>(p.proj_w + c * CH + c0);
@@ -414,27 +435,43 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                             pj[c] += w0.x * v[0] + w0.y * v[1] + w0.z * v[2] + w0.w * v[3] + w1.x * v[4] + w1.y * v[5] + w1.z * v[6] + w1.w * v[7];
                         }
                     }
-                    if (p.of32) {
-                        *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                    }
-                    if (p.oh) {
-                        // hi = round-to-nearest f16 (v_cvt_pk_f16_f32): a 1-term consumer sees half the error of a
-                        // truncated hi, a 3-term consumer does not care (lo absorbs the remainder either way)
-                        half8 hv, lv;
 #pragma unroll
-                        for (int e = 0; e < 8; e += 2) {
-                            const half2v hp = cvt_rtn(v[e], v[e + 1]);
-                            hv[e] = hp[0]; hv[e + 1] = hp[1];
-                            const half2v lp = cvt_rtn(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
-                            lv[e] = lp[0]; lv[e + 1] = lp[1];
+                    for (int e = 0; e < 8; e++) acc[ib][8 * q + e] = v[e];
+                }
+            }
+            // ---- pass 2: stores only
+            if (has_o32 || has_oh) {
+#pragma unroll
+                for (int ib = 0; ib < 8; ib++) {
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        const int c0 = 32 * ib + 16 * he + 8 * q;
+                        const long po = ((long)(2 * ib + he) * plane_px + ppix) * 16 + 8 * q;
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 8; e++) v[e] = acc[ib][8 * q + e];
+                        if (has_o32) {
+                            *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4 *>(p.of32 + orow * CH + c0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
                         }
-                        *reinterpret_cast<half8 *>(p.oh + po) = hv;
-                        if (p.ol) *reinterpret_cast<half8 *>(p.ol + po) = lv;   // not needed when every consumer is 1-term
+                        if (has_oh) {
+                            // hi = round-to-nearest f16 (v_cvt_pk_f16_f32): a 1-term consumer sees half the error of a
+                            // truncated hi, a 3-term consumer does not care (lo absorbs the remainder either way)
+                            half8 hv, lv;
+#pragma unroll
+                            for (int e = 0; e < 8; e += 2) {
+                                const half2v hp = cvt_rtn(v[e], v[e + 1]);
+                                hv[e] = hp[0]; hv[e + 1] = hp[1];
+                                const half2v lp = cvt_rtn(v[e] - (float)hp[0], v[e + 1] - (float)hp[1]);
+                                lv[e] = lp[0]; lv[e + 1] = lp[1];
+                            }
+                            *reinterpret_cast<half8 *>(p.oh + po) = hv;
+                            if (has_ol) *reinterpret_cast<half8 *>(p.ol + po) = lv;   // not needed when every consumer is 1-term
+                        }
                     }
                 }
             }
-            if (p.proj_w) {   // the two half-waves hold the two channel halves of the same pixel
+            if (has_proj) {   // the two half-waves hold the two channel halves of the same pixel
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const float t = pj[c] + __shfl_xor(pj[c], 32);
@@ -590,45 +627,49 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms,
     p.n_groups = p.gx * p.gy;
     int wg = n_workgroups > 0 ? n_workgroups : 256;
     if (wg > p.n_groups) wg = p.n_groups;
+    // epilogue variant: the combinations the render CNN's plane-to-plane layers use are specialised
+    const bool rp = resid_hi != nullptr, md = mod_w != nullptr, pj = proj_w != nullptr, lo = out_lo != nullptr;
+    int epi = 255;
+    if (!resid && !out_f32 && !pj && out_hi) {
+        if (bias && !rp && !md) epi = lo ? 16 : 0;                 // conv1, conv2a, conv3a, conv4a
+        else if (!bias && rp && md && lo) epi = 1 | 2 | 8 | 16;    // conv2b, conv3b (bias-free in the reference)
+    }
+    int dbg = 0;
+#ifdef SDN_MLP_ABLATION
+    if (const char *e1 = getenv("SDN_CONV_DBG")) dbg = atoi(e1);   // timing experiments only (re-read per call); results are wrong
+#endif
+    const dim3 grid(wg), block(64 * WAVES);
+    hipStream_t hs = (hipStream_t)stream;
+#define SDN_LAUNCH(TAPS, DBG, TERMS, EPI) hipLaunchKernelGGL((conv_kernel<TAPS, DBG, TERMS, EPI>), grid, block, 0, hs, p)
     if (taps == 1) {
-        hipLaunchKernelGGL((conv_kernel<1, 0, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
-        return sdn::check_launch("sdn_conv");
-    }
-    if (terms == 1) {
+        if (epi == 16) SDN_LAUNCH(1, 0, 3, 16);
+        else SDN_LAUNCH(1, 0, 3, 255);   // (conv4b + projection)
+    } else if (terms == 1) {
+        if (dbg && (epi == 0 || epi == 16)) {
 #ifdef SDN_MLP_ABLATION
-        const char *e1 = getenv("SDN_CONV_DBG");   // timing experiments only (re-read per call); results are wrong unless 0
-        switch (e1 ? atoi(e1) : 0) {
-            case 1: hipLaunchKernelGGL((conv_kernel<9, 1, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 2: hipLaunchKernelGGL((conv_kernel<9, 2, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 16: hipLaunchKernelGGL((conv_kernel<9, 16, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 17: hipLaunchKernelGGL((conv_kernel<9, 17, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 19: hipLaunchKernelGGL((conv_kernel<9, 19, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 3: hipLaunchKernelGGL((conv_kernel<9, 3, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 65: hipLaunchKernelGGL((conv_kernel<9, 65, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 66: hipLaunchKernelGGL((conv_kernel<9, 66, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 67: hipLaunchKernelGGL((conv_kernel<9, 67, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            case 64: hipLaunchKernelGGL((conv_kernel<9, 64, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-            default: hipLaunchKernelGGL((conv_kernel<9, 0, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        }
-        return sdn::check_launch("sdn_conv");
+            switch (dbg) {
+                case 1: SDN_LAUNCH(9, 1, 1, 16); break;
+                case 2: SDN_LAUNCH(9, 2, 1, 16); break;
+                case 3: SDN_LAUNCH(9, 3, 1, 16); break;
+                case 16: SDN_LAUNCH(9, 16, 1, 16); break;
+                case 17: SDN_LAUNCH(9, 17, 1, 16); break;
+                case 19: SDN_LAUNCH(9, 19, 1, 16); break;
+                case 64: SDN_LAUNCH(9, 64, 1, 16); break;
+                case 65: SDN_LAUNCH(9, 65, 1, 16); break;
+                case 67: SDN_LAUNCH(9, 67, 1, 16); break;
+                default: SDN_LAUNCH(9, 0, 1, 16); break;
+            }
 #endif
-        hipLaunchKernelGGL((conv_kernel<9, 0, 1>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p);
-        return sdn::check_launch("sdn_conv");
+        } else if (epi == 0) SDN_LAUNCH(9, 0, 1, 0);
+        else if (epi == 16) SDN_LAUNCH(9, 0, 1, 16);
+        else if (epi == 27) SDN_LAUNCH(9, 0, 1, 27);
+        else SDN_LAUNCH(9, 0, 1, 255);
+    } else {
+        if (epi == 16) SDN_LAUNCH(9, 0, 3, 16);
+        else if (epi == 27) SDN_LAUNCH(9, 0, 3, 27);
+        else SDN_LAUNCH(9, 0, 3, 255);
     }
-    static const int dbg = [] {
-        const char *e = getenv("SDN_CONV_DBG");   // timing experiments only; results are wrong unless 0
-        return e ? atoi(e) : 0;
-    }();
-    switch (dbg) {
-#ifdef SDN_MLP_ABLATION
-        case 1: hipLaunchKernelGGL((conv_kernel<9, 1, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 2: hipLaunchKernelGGL((conv_kernel<9, 2, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 3: hipLaunchKernelGGL((conv_kernel<9, 3, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 16: hipLaunchKernelGGL((conv_kernel<9, 16, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-        case 19: hipLaunchKernelGGL((conv_kernel<9, 19, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-#endif
-        default: hipLaunchKernelGGL((conv_kernel<9, 0, 3>), dim3(wg), dim3(64 * WAVES), 0, (hipStream_t)stream, p); break;
-    }
+#undef SDN_LAUNCH
     return sdn::check_launch("sdn_conv");
 }
 
