@@ -177,8 +177,7 @@ __device__ __forceinline__ void stream_chunk(const ConvParams &p, Stream &st, Sl
             st.w = 0;
             st.off = 0;
         }
-        sn.voff = voff_sel;
-        asm volatile("" ::"s"(st.w), "s"(st.off), "v"(sn.voff));
+        asm volatile("" ::"s"(st.w), "s"(st.off));
     }
 }
 
@@ -300,6 +299,19 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
     unsigned voff_n = grp_n < p.n_groups ? (unsigned)lane_pixel_offset(p, grp_n, wave, lane, pyn, pxn) - tap0 : voff;
 
     const int ksteps = p.ksteps;
+    // De-phase the workgroups.  All of them start together and take the same time per patch, so their epilogues coincide:
+    // 256 x 128 KiB (hi plane) leave the chip in one burst every patch time, and the stores back up behind the fabric.
+    // Workgroups that have one patch less than the longest-running ones (n_groups mod grid of them have one more) start
+    // late by a fraction of a patch time: it costs nothing (they still finish first) and spreads the bursts.
+    {
+        const int n_mine = (p.n_groups - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int n_max = (p.n_groups + (int)gridDim.x - 1) / (int)gridDim.x;
+        if (!(DBG & 2048) && n_mine < n_max) {
+            const int phase = (blockIdx.x >> 3) & 15;                    // blockIdx & 7 is the XCD
+            const int naps = (phase * (ksteps * 1400 + 20000)) >> (4 + 13);   // s_sleep 127 ~ 8 k cycles
+            for (int i = 0; i < naps; i++) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     Stream st{0ul, 0, 0};
     int pos_issue = 0, pos_use = 0;
 #pragma unroll
@@ -336,8 +348,12 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
             for (int par = 0; par < 2; par++) {
                 const int kt = kt2 + par;
                 // `si`: the slot fetched during this one (AHEAD slots on, possibly of the next patch); `sn`: the one after it
+                // (the per-lane pixel offsets are chosen HERE, not a slot ahead: with ksteps == AHEAD, the 64-channel conv1, the
+                // last slot of a patch prepares a slot of the patch after the next one, whose offsets are not known before
+                // the epilogue)
                 SlotIssue sn;
-                const unsigned voff_sel = kt + 1 + AHEAD < ksteps ? voff : voff_n;
+                si.voff = kt + AHEAD < ksteps ? voff : voff_n;
+                const unsigned voff_sel = si.voff;
                 const unsigned slot = lds_lane + pos_use * SLOT_BYTES;
                 pos_use = pos_use + 1 == NSLOT ? 0 : pos_use + 1;
                 const unsigned slot_n = lds_lane + pos_use * SLOT_BYTES;

@@ -120,7 +120,7 @@ def test_mfma_cnn_matches_torch_cnn(renderer, terms3x3, bound):
     single round-to-nearest f16 product (tools/precision_study.py predicts ~7e-5 rms, < 5e-4 max)."""
     from scenedreamer_amd.cnn import MfmaCNN
     torch.manual_seed(0)
-    for hw in ((37, 53), (64, 96), (128, 200)):
+    for hw in ((37, 53), (64, 96), (128, 200), (300, 520)):   # the last: 627 patches on 256 workgroups (patch transitions)
         x = (torch.rand(1, hw[0], hw[1], 64, device="cuda") * 2 - 1)
         ref = renderer.render_cnn(x)
         got = MfmaCNN(renderer, terms3x3)(x)
