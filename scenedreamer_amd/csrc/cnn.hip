@@ -334,7 +334,14 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
     half8 b[2][2];
     const unsigned lds_lane = lds_addr(lds) + lane * 16;
     const unsigned b_off = A_BYTES + wave * B_BYTES;
-    bool primed = false, first_patch = true;
+    bool first_patch = true;
+    // fragments of the kernel's very first slot (from then on every slot's first fragments are read during the slot before it)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * DMA_PER_SLOT) : "memory");
+    __builtin_amdgcn_s_barrier();
+    ds_read16<0>(b[0][0], lds_lane + b_off);
+    ds_read16<1024>(b[0][1], lds_lane + b_off);
+    lds_unit<0>(lds_lane, a[0]);
+    lds_unit<1>(lds_lane, a[1]);
 
     while (true) {
         f32x16 acc[8];
@@ -366,13 +373,6 @@ __global__ __launch_bounds__(512, 2) void conv_kernel(const ConvParams p) {
                 if (kt >= AHEAD - 1 || first_patch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 2) * DMA_PER_SLOT) : "memory");
                 if constexpr (!(DBG & 2)) __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (!primed) {   // very first k-step of the kernel only
-                    ds_read16<0>(b[0][0], slot + b_off);
-                    ds_read16<1024>(b[0][1], slot + b_off);
-                    lds_unit<0>(slot, a[0]);
-                    lds_unit<1>(slot, a[1]);
-                    primed = true;
-                }
                 conv_unit<TAPS, TERMS, DBG, 0>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane, p, st, sn, lds, pos_issue, voff_sel, ksteps);
                 conv_unit<TAPS, TERMS, DBG, 1>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane, p, st, sn, lds, pos_issue, voff_sel, ksteps);
                 conv_unit<TAPS, TERMS, DBG, 2>(acc, a, b[par], b[par ^ 1], slot, slot_n, b_off, si, wave, lane, p, st, sn, lds, pos_issue, voff_sel, ksteps);

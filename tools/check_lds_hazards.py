@@ -6,8 +6,8 @@ hand-written `s_waitcnt lgkmcnt(N)` keeps an instruction from reading a register
 script compiles the kernels to ISA and replays every kernel linearly: each ds_read* pushes its destination registers
 on an in-order queue, `s_waitcnt lgkmcnt(N)` retires all but the newest N entries (LDS returns in order; SMEM loads
 are treated as queue entries too, conservatively), and any instruction that reads OR overwrites a register still in
-the queue is reported.  Branch targets are handled conservatively: the queue is carried across labels as is (the
-kernels' loops are straight-line bodies).
+the queue is reported.  The replay follows the control-flow graph: every basic block is replayed from every distinct
+queue that can reach it (loops until the set of (block, queue) states stops growing).
 
     python tools/check_lds_hazards.py            # exit status 1 if a hazard is found
 """
@@ -19,7 +19,9 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = {"field.hip": ["-fno-slp-vectorize"], "cnn.hip": []}
-KERNELS = ("mlp_kernelILi0ELi3", "mlp_kernelILi0ELi2", "mlp_kernelILi0ELi6", "sky_kernelILi0ELi0", "sky_kernelILi0ELi1", "conv_kernelILi9ELi0ELi3", "conv_kernelILi9ELi0ELi1", "conv_kernelILi1ELi0ELi3")
+KERNELS = ("mlp_kernelILi0ELi3", "mlp_kernelILi0ELi2", "mlp_kernelILi0ELi6", "sky_kernelILi0ELi0", "sky_kernelILi0ELi1", "conv_kernelILi9ELi0ELi3ELi16E", "conv_kernelILi9ELi0ELi3ELi27E", "conv_kernelILi9ELi0ELi3ELi255E",
+           "conv_kernelILi9ELi0ELi1ELi0E", "conv_kernelILi9ELi0ELi1ELi16E", "conv_kernelILi9ELi0ELi1ELi27E", "conv_kernelILi9ELi0ELi1ELi255E",
+           "conv_kernelILi1ELi0ELi3ELi16E", "conv_kernelILi1ELi0ELi3ELi255E")
 REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
 
 
@@ -33,8 +35,10 @@ def regs_of(text):
     return out
 
 
-def check_kernel(name, lines):
-    queue, problems, n_reads = [], [], 0
+def run_block(lines, queue, problems):
+    """Replay one basic block from the pending-read queue `queue` (list of (frozenset of registers, line)); returns the
+    queue at its end.  Hazards are appended to `problems` (a dict keyed by line, so a line is reported once)."""
+    queue = list(queue)
     for ln, raw in lines:
         line = raw.split(";")[0].strip()
         if not line or line.endswith(":") or line.startswith("."):
@@ -49,26 +53,91 @@ def check_kernel(name, lines):
         pending = set().union(*[q[0] for q in queue]) if queue else set()
         if op.startswith("ds_read") or op.startswith("ds_load"):
             dst, _, srcs = rest.partition(",")
-            used = regs_of(srcs)
-            if used & pending:
-                problems.append((ln, raw.strip(), "address register pending"))
-            d = regs_of(dst)
+            if regs_of(srcs) & pending:
+                problems.setdefault((ln, "address register pending"), raw.strip())
+            d = frozenset(regs_of(dst))
             if d & pending:
-                problems.append((ln, raw.strip(), "overwrites a pending destination"))
+                problems.setdefault((ln, "overwrites a pending destination"), raw.strip())
             queue.append((d, ln))
-            n_reads += 1
             continue
-        if op.startswith("s_load") or op.startswith("s_buffer_load"):
-            queue.append((set(), ln))   # counts on lgkmcnt, scalar destination
+        if op.startswith("s_load") or op.startswith("s_buffer_load") or op == "s_memtime":
+            queue.append((frozenset(), ln))   # counts on lgkmcnt, scalar destination
             continue
         if op.startswith("ds_"):        # ds_write / ds_bpermute ...: count, no vector destination tracked here
             if regs_of(rest) & pending:
-                problems.append((ln, raw.strip(), "reads a pending register"))
-            queue.append((regs_of(rest.split(",")[0]) if "permute" in op or "swizzle" in op else set(), ln))
+                problems.setdefault((ln, "reads a pending register"), raw.strip())
+            queue.append((frozenset(regs_of(rest.split(",")[0])) if "permute" in op or "swizzle" in op else frozenset(), ln))
             continue
         if regs_of(rest) & pending:
-            problems.append((ln, raw.strip(), "touches a pending register"))
-    return n_reads, problems
+            problems.setdefault((ln, "touches a pending register"), raw.strip())
+    return queue
+
+
+def check_kernel(name, lines):
+    """field.hip's kernels: one linear replay in text order (their blocks are laid out in execution order and the loops are
+    straight-line bodies; the CFG walk below does not finish on 1 400 reads).  cnn.hip's: every path through the kernel's
+    control-flow graph (hipcc rotates its k loop, text order is not execution order)."""
+    if not name.startswith("conv_kernel"):
+        problems = {}
+        run_block(lines, [], problems)
+        n = sum(1 for _, raw in lines if raw.split(";")[0].strip().startswith(("ds_read", "ds_load")))
+        return n, [(ln, raw, why) for (ln, why), raw in sorted(problems.items())]
+    return check_kernel_cfg(name, lines)
+
+
+def check_kernel_cfg(name, lines):
+    """Every path through the kernel's control-flow graph: basic blocks are replayed from each distinct pending-read queue
+    that reaches them (work list over (block, queue) pairs; the queues are finite sequences and a loop reaches its
+    steady state after a couple of trips, so this terminates quickly)."""
+    # ---- basic blocks: a block starts at a label or behind a branch
+    blocks, cur, label_of = [], [], {}
+    def close():
+        nonlocal cur
+        if cur:
+            blocks.append(cur)
+            cur = []
+    for ln, raw in lines:
+        t = raw.split(";")[0].strip()
+        if t.endswith(":") and not t.startswith("."):
+            continue
+        if t.endswith(":"):
+            close()
+            label_of[t[:-1]] = len(blocks)
+            continue
+        cur.append((ln, raw))
+        op = t.split(" ")[0] if t else ""
+        if op.startswith("s_cbranch") or op in ("s_branch", "s_endpgm"):
+            close()
+    close()
+    def successors(i):
+        last = next((r.split(";")[0].strip() for _, r in reversed(blocks[i]) if r.split(";")[0].strip()), "")
+        op, _, tgt = last.partition(" ")
+        out = []
+        if op == "s_endpgm":
+            return out
+        if op == "s_branch":
+            return [label_of[tgt.strip()]]
+        if op.startswith("s_cbranch"):
+            out.append(label_of[tgt.strip()])
+        if i + 1 < len(blocks):
+            out.append(i + 1)
+        return out
+    problems, seen, work = {}, set(), [(0, ())]
+    n_reads = sum(1 for _, raw in lines if raw.split(";")[0].strip().startswith(("ds_read", "ds_load")))
+    while work:
+        i, q = work.pop()
+        key = (i, tuple(r for r, _ in q))
+        if key in seen:
+            continue
+        seen.add(key)
+        if len(seen) > 200000:
+            problems[(0, "state explosion")] = "more than 200000 (block, queue) states"
+            break
+        out = tuple(run_block(blocks[i], q, problems))
+        for j in successors(i):
+            if j < len(blocks):   # (a label behind the last instruction: the kernel's end)
+                work.append((j, out))
+    return n_reads, [(ln, raw, why) for (ln, why), raw in sorted(problems.items())]
 
 
 def check_prefetch_agprs(lines, lo=190, hi=255):
