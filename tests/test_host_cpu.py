@@ -259,3 +259,39 @@ def test_mp4_writer_roundtrip(tmp_path):
         assert np.abs(g.astype(np.int32) - ref).mean() < 2.0          # JPEG quality 92, 4:4:4
     raw = open(tmp_path / "out.mp4", "rb").read()
     assert raw[4:8] == b"ftyp" and b"moov" in raw and b"co64" in raw
+
+
+def test_hazard_checker_finds_planted_hazards():
+    """The checker itself: a rotated loop whose text order is not its execution order (the shape hipcc gives cnn.hip's
+    k loop).  Clean as written; with the loop's wait weakened, or with a read landing in a fragment that is still pending,
+    the control-flow walk must report it."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_lds_hazards", os.path.join(ROOT, "tools", "check_lds_hazards.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+
+    def kernel(wait, late_dst="v[20:23]"):
+        text = f"""
+        ds_read_b128 v[8:11], v0 offset:0
+        ds_read_b128 v[12:15], v0 offset:1024
+        s_branch .LBB0_2
+.LBB0_1:
+        s_waitcnt lgkmcnt({wait})
+        v_mfma_f32_32x32x16_f16 v[100:115], v[8:11], v[12:15], v[100:115]
+        ds_read_b128 v[8:11], v0 offset:0
+        ds_read_b128 v[12:15], v0 offset:1024
+.LBB0_2:
+        s_waitcnt lgkmcnt(2)
+        ds_read_b128 {late_dst}, v0 offset:2048
+        s_cbranch_scc1 .LBB0_1
+        s_waitcnt lgkmcnt(0)
+        v_mov_b32_e32 v1, v20
+        """
+        return list(enumerate(text.strip("\n").split("\n"), 1))
+
+    n, problems = chk.check_kernel("conv_kernel_test", kernel(0))
+    assert n == 5 and problems == []
+    _, problems = chk.check_kernel("conv_kernel_test", kernel(2))          # the MFMA reads fragments still in flight
+    assert any("touches a pending register" in why for _, _, why in problems)
+    _, problems = chk.check_kernel("conv_kernel_test", kernel(0, "v[8:11]"))   # lands in a fragment whose read is in flight
+    assert any("overwrites a pending destination" in why for _, _, why in problems)
