@@ -143,6 +143,7 @@ def cpu_baseline(args, weights, scene, z, genc):
     t_tiles = time.time() - t0 - t_frame
     sampled = sum((im.shape[2] + 30) * (im.shape[3] + 30) for (_, _, im) in got.values())
     fps = 1.0 / (t_frame + t_tiles * frame_tile_rays / sampled)
+    cpu_baseline.tiles, cpu_baseline.pose = got, pose       # the oracle's pixels: main() measures the GPU path's error on them
     return {"value": fps, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{args.width}x{args.height}, {args.samples} samples/ray, scene_size {args.scene_size}: ray casting + sky "
                       f"pre-pass of the whole padded frame ({t_frame:.2f} s) + {len(picks)} of the reference's {nh * nw} "
@@ -216,6 +217,10 @@ def main():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
+
+    if world > 1 and mode == "fused":
+        # one decision of the render CNN's precision gate for the whole job (every rank renders the same frame; MAX over ranks)
+        sdist.agree_cnn_precision(R, poses[0], (540, 960) if tile_parallel else hw, args.samples)
 
     def render_one(pz):
         if tile_parallel:
@@ -299,7 +304,9 @@ def main():
         # next frame's sky MLP / sample encode on the side stream in the timed region; `stage_ms.cnn` is the same CNN alone
         px = (hw[0] + 8) * (hw[1] + 8) if args.apron == "minimal" else (hw[0] + 30) * (hw[1] + 30)
         ms_cnn = ms_of("render_cnn")
-        roof_cnn = {"bound": "mfma", "kernel": "conv_kernel<1|9> x 7 (RenderCNN; 1x1 layers 3-term f16, 3x3 layers one f16 product)",
+        t3 = (R.cnn_calibration or {}).get("terms3x3") or getattr(R, "cnn_terms3x3", None) or os.environ.get("SDN_CNN_TERMS")
+        roof_cnn = {"bound": "mfma", "kernel": f"conv_kernel<1|9> x 7 (RenderCNN; 1x1 layers 3-term f16, 3x3 layers {t3}-term f16)",
+                    "precision_gate": R.cnn_calibration,
                     "pixels": px, "algorithmic_flop_per_pixel": 5015040, "avg_ms_in_timed_region": ms_cnn,
                     "achieved": px * 5015040 / (ms_cnn * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
                     "frac": px * 5015040 / (ms_cnn * 1e-3) / 1e12 / 2500.0,
@@ -345,6 +352,24 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, weights, scene, R.z.cpu().numpy(), R.global_enc.cpu().numpy())
+            # a reduced-precision internal path is named (`dtype`) together with its MEASURED max-abs error:
+            # the same pose through the timed path (pipelined render_frames, this volume, this apron) against the
+            # oracle's pixels of the tiles the CPU baseline has just rendered
+            if tile_parallel:
+                gpu_img = render_one(cpu_baseline.pose)
+            elif mode == "fused" and not args.no_overlap:
+                gpu_img = [im.clone() for im in R.render_frames([cpu_baseline.pose] * 2, hw, args.samples, mode=mode, apron=args.apron)][1]
+            else:
+                gpu_img = R.render_frame(cpu_baseline.pose, hw, args.samples, mode=mode, apron=args.apron)
+            gpu_img = gpu_img.cpu().numpy()
+            errs = {t: float(np.abs(gpu_img[:, :, r0:r0 + im.shape[2], c0:c0 + im.shape[3]] - im.numpy()).max())
+                    for t, (r0, c0, im) in cpu_baseline.tiles.items()}
+            out["precision"] = {"max_abs_err": max(errs.values()), "bound": 1e-3, "quantity": "image (tanh output, range [-1, 1])",
+                                "per_tile": {f"{t[0]},{t[1]}": e for t, e in errs.items()},
+                                "where_measured": f"{len(errs)} tiles of the reference's tile grid ({sum(im.shape[2] * im.shape[3] for _, _, im in cpu_baseline.tiles.values())} "
+                                                  f"of {hw[0] * hw[1]} pixels), pose 8 of the 40-pose orbit, this run's GPU path vs the fp32 "
+                                                  "CPU oracle (reference-literal tiling); one whole frame (40 of 40 tiles) and configs 3 / 5: "
+                                                  "tests/test_config_parity_gpu.py"}
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

@@ -179,7 +179,10 @@ int sdn_field_pack_weights_mx(const float *w1, const float *const *wh5_host, con
  * rayflag u8 [R].  Sample placement = mc_utils.sample_depth_batched(nsamples = num_samples + 1, use_box_boundaries =
  * False): deterministic (inference) with u_dev = NULL and lin_dev f32 [num_samples+1] = linspace(0,1,num_samples+3)[1:-1];
  * stochastic / stratified (training, mc_utils.py:121-125) with u_dev f32 [R, num_samples+1] = the caller's torch.rand draw
- * and lin_dev = linspace(0,1,num_samples+2)[:-1].
+ * and lin_dev = linspace(0,1,num_samples+2)[:-1]; strat_division selects how `rand_samples / nsamples` (mc_utils.py:123,
+ * tensor / Python scalar) is evaluated: 0 = multiplication by the float32 reciprocal, what PyTorch does on a CUDA tensor
+ * (the reference's GPU path); 1 = IEEE division, what PyTorch does on a CPU tensor (the goldens recorded from the
+ * reference's CPU run).  They differ by at most 1 ulp, and only when nsamples is not a power of two.
  * window_host: NULL (the n_rays rays are rays 0..n_rays-1 of voxel_id / depth2 / raydirs), or host int32[5]
  *   {n_src, pitch, first, cols, ray0}: the arrays hold n_src rays (the whole padded frame the ray marcher wrote, as the
  *   reference's per-frame voxlib call does, scenedreamer.py:576-590) and local ray r is ray w = ray0 + r of a window of
@@ -189,13 +192,15 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
                      int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
-                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, sdn_stream_t stream);
+                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, int32_t strat_division,
+                     sdn_stream_t stream);
 /* mc_utils.sample_depth_batched (imaginaire/model_utils/gancraft/mc_utils.py:82-151, use_box_boundaries = False) as an op:
  * depth2 dev f32 [2,R,M] -> rand_depth, new_dists dev f32 [R, n_points-1], idx dev i64 [R, n_points-1] (raw values: NaN
  * depths of rays without a hit are left for the caller to zero, scenedreamer.py:350-352).  lin_dev / u_dev as above with
- * n_points = nsamples of the reference call. */
+ * n_points = nsamples of the reference call, strat_division as for sdn_field_encode. */
 int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_dev, int32_t n_rays, int32_t max_blocks,
-                     int32_t n_points, float sample_depth, float *rand_depth, float *new_dists, int64_t *idx, sdn_stream_t stream);
+                     int32_t n_points, float sample_depth, float *rand_depth, float *new_dists, int64_t *idx,
+                     int32_t strat_division, sdn_stream_t stream);
 /* sky_c dev f32 [R,64] = sky_net output per ray; net_out dev f32 [R,64]; n_workgroups <= 0 -> one per CU.
  * colour_terms: products of the colour layers fc_5 / fc_6 (LightningMLP.forward, layers.py:117-124): 3 = the 3-term f16 split
  *   like every other layer; 2 = without Whi.Xlo; 6 = Whi.Xhi in f16 + the two correction terms as block-scaled fp6

@@ -23,6 +23,14 @@ Variants (floating-point contraction decides discrete outcomes, DESIGN.md sectio
 The modules are what `oracle/ref_harness.install("ref")` puts under the unmodified Python
 reference.  /root/reference exists only in the build container; on the GPU box the prebuilt
 .so files (git-ignored, shipped by gpurun) are used as they are.
+
+stage_pytree() stages the reference's PYTHON side the same way: the modules the generator imports
+(imaginaire/**.py + its label tables, gridencoder/*.py, encoding.py, activation.py, the inference
+config) are packed, unchanged, into ONE archive oracle/_ref/pytree.zip -- a built artefact like the
+.so files: git-ignored, shipped by gpurun, never unpacked inside the repo.  oracle/ref_harness
+unpacks it into a temporary directory when /root/reference is absent, which is how
+tests/test_shim_replay_gpu.py::test_unmodified_generator_on_hip_shims gets the UNMODIFIED generator
+next to a GPU.
 """
 import os
 import re
@@ -50,8 +58,41 @@ VARIANTS = {
 _LAUNCH = re.compile(r"([A-Za-z_]\w*(?:<[^<>;(){}]*>)?)\s*<<<(.*?)>>>", re.S)
 
 
+PYTREE = os.path.join(OUT, "pytree.zip")
+_PY_TOP = ("encoding.py", "activation.py", "configs/scenedreamer_inference.yaml")
+_PY_DIRS = {"imaginaire": (".py", ".csv", ".json", ".yaml"), "gridencoder": (".py",)}
+
+
 def available():
     return os.path.isdir(VOXLIB) and os.path.isdir(GRID)
+
+
+def stage_pytree(force=False, verbose=True):
+    """Pack the reference's Python tree (unchanged files, paths relative to the reference root) into oracle/_ref/pytree.zip."""
+    import zipfile
+    if not available():
+        if os.path.exists(PYTREE):
+            return PYTREE
+        raise RuntimeError("oracle/_ref: /root/reference is absent and no staged pytree.zip is present")
+    files = [f for f in _PY_TOP if os.path.isfile(os.path.join(REFERENCE, f))]
+    for d, exts in _PY_DIRS.items():
+        for base, _, names in os.walk(os.path.join(REFERENCE, d)):
+            if "__pycache__" in base:
+                continue
+            files += [os.path.relpath(os.path.join(base, n), REFERENCE) for n in names if n.endswith(exts)]
+    files.sort()
+    newest = max(os.path.getmtime(os.path.join(REFERENCE, f)) for f in files)
+    if not force and os.path.exists(PYTREE) and os.path.getmtime(PYTREE) >= max(newest, os.path.getmtime(__file__)):
+        return PYTREE
+    os.makedirs(OUT, exist_ok=True)
+    tmp = PYTREE + ".tmp"
+    with zipfile.ZipFile(tmp, "w", zipfile.ZIP_DEFLATED) as z:
+        for f in files:
+            z.write(os.path.join(REFERENCE, f), f)
+    os.replace(tmp, PYTREE)
+    if verbose:
+        print(f"[oracle/_ref] staged {len(files)} files of the reference's Python tree -> {os.path.relpath(PYTREE, HERE)}", flush=True)
+    return PYTREE
 
 
 def module_path(name, variant="nofma"):
@@ -137,3 +178,4 @@ def build(force=False, variants=("nofma", "fma"), verbose=True):
 
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    stage_pytree(force="--force" in sys.argv)

@@ -1,8 +1,9 @@
-"""Import the UNMODIFIED reference generator on CPU (build container only).
+"""Import the UNMODIFIED reference generator (Python side) -- from /root/reference in the build
+container, from the staged archive oracle/_ref/pytree.zip (oracle/build_ref.stage_pytree: the same
+files, unchanged, shipped like the prebuilt oracle/_ref/*.so) on the GPU box.
 
 TEST INFRASTRUCTURE: used by oracle/make_golden.py and by the `needs_reference`
-tests.  /root/reference does not exist on the GPU box, so nothing reachable from
-the -m gpu tests, smoke() or bench.py imports this module.
+tests; nothing in the product package, smoke() or bench.py imports this module.
 
 Six top-level modules the reference imports are absent here:
 cv2, imageio, upfirdn2d_cuda, bias_act_cuda (never called on the path: inert
@@ -17,10 +18,33 @@ import numpy as np
 import torch
 
 REFERENCE = "/root/reference"
+_PYTREE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "pytree.zip")
+_unpacked = None
 
 
 def available():
-    return os.path.isdir(os.path.join(REFERENCE, "imaginaire"))
+    return os.path.isdir(os.path.join(REFERENCE, "imaginaire")) or os.path.exists(_PYTREE)
+
+
+def root():
+    """Directory that holds the reference's Python tree: /root/reference where it exists, else the staged archive
+    unpacked into a temporary directory (once per process, removed at exit; never inside the repo)."""
+    global _unpacked
+    if os.path.isdir(os.path.join(REFERENCE, "imaginaire")):
+        return REFERENCE
+    if _unpacked is None:
+        import atexit
+        import shutil
+        import tempfile
+        import zipfile
+        if not os.path.exists(_PYTREE):
+            raise RuntimeError("neither /root/reference nor oracle/_ref/pytree.zip is present")
+        d = tempfile.mkdtemp(prefix="sdn_ref_pytree_")
+        with zipfile.ZipFile(_PYTREE) as z:
+            z.extractall(d)
+        atexit.register(shutil.rmtree, d, True)
+        _unpacked = d
+    return _unpacked
 
 
 _installed = None
@@ -111,8 +135,8 @@ def install(native="oracle"):
         ge.grid_encode_backward = grid_encode_backward
         sys.modules["_gridencoder"] = ge
 
-    if REFERENCE not in sys.path:
-        sys.path.insert(0, REFERENCE)
+    if root() not in sys.path:
+        sys.path.insert(0, root())
 
 
 def build_generator(weights=None, scene=None):
@@ -121,7 +145,7 @@ def build_generator(weights=None, scene=None):
     import warnings
     warnings.filterwarnings("ignore")
     from imaginaire.config import Config
-    cfg = Config(os.path.join(REFERENCE, "configs/scenedreamer_inference.yaml"))
+    cfg = Config(os.path.join(root(), "configs/scenedreamer_inference.yaml"))
     from imaginaire.generators.scenedreamer import Generator
     import contextlib
     import io

@@ -53,8 +53,9 @@ _SIGNATURES = {
     "sdn_field_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_field_pack_weights_mx": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_field_encode": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
-                               ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "sdn_sample_depth": (c_i, [c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f, c_p, c_p, c_p, c_p]),
+                               ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, c_p]),
+    "sdn_sample_depth": (c_i, [c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f, c_p, c_p, c_p,
+                               ctypes.c_int32, c_p]),
     "sdn_field_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                             ctypes.c_float, c_p, ctypes.c_int32, c_p, c_p, c_p, c_p]),
     "sdn_sky_packed_weight_bytes": (ctypes.c_size_t, []),

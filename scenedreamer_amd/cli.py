@@ -7,7 +7,9 @@
     python -m torch.distributed.run --nproc-per-node N ... -m scenedreamer_amd.cli ...     # frames sharded over GPUs
 
 Without --checkpoint (none is available offline) a seeded synthetic scene and random-init weights of the reference's
-shapes are used.  Frames are written as <output_dir>/rgb_render/%05d.png by a background writer."""
+shapes are used.  Outputs as the reference writes them (scenedreamer.py:557-564, :629-632): <output_dir>/rgb_render/%05d.png,
+semantic_map.png, height_map.png, style.npy and, on a single rank, <output_dir>/rgb_render.mp4 at 10 fps -- all by a
+background writer."""
 import argparse
 import os
 
@@ -38,7 +40,7 @@ def main():
     dev = torch.device("cuda", local)
     from . import camera, synth
     from . import dist as sdist
-    from .output import FrameWriter
+    from .output import FrameWriter, write_scene_maps
     from .renderer import Renderer
 
     scene = weights = style = None
@@ -65,9 +67,13 @@ def main():
     R = Renderer(weights, scene, dev)
     R.set_style(style)
     poses = camera.eval_camera_poses(scene, maxstep=args.cam_maxstep, pattern=args.camera_mode, cam_ang=args.cam_ang)
+    if world > 1 and args.mode == "fused":     # one decision of the render CNN's precision gate for all ranks
+        sdist.agree_cnn_precision(R, poses[0], tuple(args.resolution_hw), args.num_samples)
     out = os.path.join(args.output_dir, "rgb_render")
-    writer = FrameWriter(out)
+    # (a sharded job writes PNGs from every rank; the video needs the frames in one place, so only a single rank writes it)
+    writer = FrameWriter(out, video_path=(out + ".mp4") if world == 1 else None, fps=10)
     if rank == 0:
+        write_scene_maps(out, scene)                                  # scenedreamer.py:562-563
         np.save(os.path.join(out, "style.npy"), np.asarray(style))    # scenedreamer.py:564
     mine = sdist.shard_frames(range(len(poses)), rank, world)
     hw = tuple(args.resolution_hw)

@@ -3,11 +3,12 @@
 conv2a/2b/3a/3b (3x3), conv4a/4b (1x1) with conv4 (256->3) + tanh folded into conv4b's epilogue; activations travel
 as f16 hi/lo planes.
 
-Precision profile (`terms3x3`): the 1x1 layers always use the 3-term f16 split; the four 3x3 layers use ONE term
-(Whi.Xhi, both rounded to nearest) by default -- measured image error vs the fp32 CNN ~7e-5 rms / <5e-4 max at a third
-of the MFMAs (tools/precision_study.py) -- or the 3-term split with terms3x3=3 (< 2e-5)."""
+Precision profile (`terms3x3`): the 1x1 layers always use the 3-term f16 split; the four 3x3 layers use either the
+3-term split (< 2e-5 from the fp32 CNN) or ONE term (Whi.Xhi, both rounded to nearest: a third of the MFMAs; measured
+image error vs the fp32 CNN ~7e-5 rms / < 5e-4 max on the synthetic weights, tools/precision_study.py).  The 1-term form
+is lossy in a weight-dependent way, so which one runs is decided per style by Renderer.mfma_cnn (a measured gate), not
+here; this class takes the decision as `terms3x3`."""
 import ctypes
-import os
 
 import torch
 
@@ -18,10 +19,8 @@ _LAYERS = {"conv1": (64, 1), "conv2a": (256, 9), "conv2b": (256, 9), "conv3a": (
 
 
 class MfmaCNN:
-    def __init__(self, R, terms3x3=None):
+    def __init__(self, R, terms3x3):
         self.R = R
-        if terms3x3 is None:
-            terms3x3 = int(os.environ.get("SDN_CNN_TERMS", "1"))
         assert terms3x3 in (1, 3)
         self.terms = {n: (terms3x3 if taps == 9 else 3) for n, (_, taps) in _LAYERS.items()}
         lib = capi.lib()

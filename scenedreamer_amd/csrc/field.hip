@@ -113,6 +113,7 @@ struct EncParams {
     float ori[3], delim[3];
     float sample_depth, dists_scale;
     int32_t genc_oob;          // global_enc outside [0,1] after mapping: every feature is zero
+    int32_t ieee_div;          // stochastic sampling: rand / nsamples as an IEEE division (CPU reference) instead of * (1/n)
     const float *lin;          // dev [ns+1]  deterministic: linspace(0,1,ns+3)[1:-1]; stochastic: linspace(0,1,ns+2)[:-1]
     const float *u;            // dev [R][ns+1] uniform randoms of the training-time stratified sampling, or nullptr
     const float *scales;       // dev [16]    per-level scale, exp2f(l*S)*H-1 evaluated on the host
@@ -353,14 +354,19 @@ struct Placed {
 
 // Position of stratified point i in [0,1) (mc_utils.py:116-125): deterministic -> lin[i]; stochastic (training)
 // -> rand / nsamples + linspace(0, 1, nsamples + 1)[i], `u` being the caller's torch.rand draw for this ray.
-__device__ __forceinline__ float strat_pos(const float *lin, const float *u, int n_points, int i) {
+// `rand_samples / nsamples` (tensor / Python scalar) is evaluated by PyTorch as a MULTIPLICATION by the float32 reciprocal on
+// a CUDA tensor (BinaryDivTrueKernel.cu: CPU-scalar fast path, a * (1 / b)) and as an IEEE division on a CPU tensor; the
+// two differ by 1 ulp when nsamples is not a power of two.  n_div = +nsamples: the CUDA reference's form (strat_division
+// 0 of the entry points, the default of the host wrappers); n_div = -nsamples: the CPU form (strat_division 1), which the
+// goldens recorded from the reference's CPU run were produced with.
+__device__ __forceinline__ float strat_pos(const float *lin, const float *u, int n_div, int i) {
 #pragma clang fp contract(off)
     if (u == nullptr) return lin[i];
-    const float q = u[i] / (float)n_points;
+    const float q = n_div > 0 ? u[i] * (1.0f / (float)n_div) : u[i] / (float)(-n_div);
     return q + lin[i];
 }
 
-__device__ __forceinline__ Placed place_sample(const RayBoxes &rb, int M, const float *lin, const float *u, int n_points, int sidx,
+__device__ __forceinline__ Placed place_sample(const RayBoxes &rb, int M, const float *lin, const float *u, int n_div, int sidx,
                                                float sample_depth) {
 #pragma clang fp contract(off)
     // mc_utils.py:101-107.  torch.cumsum on the CPU (what the oracle and the golden vectors were produced
@@ -383,7 +389,7 @@ __device__ __forceinline__ Placed place_sample(const RayBoxes &rb, int M, const 
     }
     const float total = fminf(run, sample_depth);
     // :118-135 deterministic stratified points and their midpoints
-    const float s0 = strat_pos(lin, u, n_points, sidx) * total, s1 = strat_pos(lin, u, n_points, sidx + 1) * total;
+    const float s0 = strat_pos(lin, u, n_div, sidx) * total, s1 = strat_pos(lin, u, n_div, sidx + 1) * total;
     const float mid = (s1 + s0) / 2.f;
     Placed o;
     o.dist = s1 - s0;
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
     for (int ch = 0; ch < p.nch; ch++) {
         const int sidx = ch * SAMP_PER_STEP + (j & 3);
         const bool valid = ray_ok && sidx < p.ns;
-        const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)rl * (p.ns + 1) : nullptr, p.ns + 1, valid ? sidx : 0,
+        const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)rl * (p.ns + 1) : nullptr, p.ieee_div ? -(p.ns + 1) : p.ns + 1, valid ? sidx : 0,
                                        p.sample_depth);
         const float wx = mul_add_exact(d0, pl.depth, p.ori[0]);  // scenedreamer.py:354
         const float wy = mul_add_exact(d1, pl.depth, p.ori[1]);
@@ -554,6 +560,7 @@ struct SampleParams {
     float *new_dists;      // [R, n_points - 1]
     int64_t *idx;          // [R, n_points - 1]
     int32_t R, M, n_points;
+    int32_t ieee_div;
     float sample_depth;
 };
 
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(256) void sample_depth_kernel(const SampleParams p)
     const float *u = p.u ? p.u + (size_t)ray * p.n_points : nullptr;
     const int ns = p.n_points - 1;
     for (int i = 0; i < ns; i++) {
-        Placed pl = place_sample(rb, p.M, p.lin, u, p.n_points, i, p.sample_depth);
+        Placed pl = place_sample(rb, p.M, p.lin, u, p.ieee_div ? -p.n_points : p.n_points, i, p.sample_depth);
         // the op returns the RAW values: NaN depths of rays that hit nothing are zeroed by the caller (scenedreamer.py:350-352)
         // and the box index is the count itself, mc_utils.py:139 (place_sample clamps it for the label lookup)
         p.new_dists[(size_t)ray * ns + i] = pl.dist;
@@ -1977,7 +1984,9 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
                      int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
-                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, sdn_stream_t stream) {
+                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, int32_t strat_division,
+                     sdn_stream_t stream) {
+    SDN_REQUIRE(strat_division == 0 || strat_division == 1, "sdn_field_encode: strat_division must be 0 (x * (1/n)) or 1 (x / n)");
     SDN_REQUIRE(voxel_id && depth2 && raydirs && lut1024 && table3 && scales_dev && genc_host && cam_ori_host &&
                     voxel_dims_host && lin_dev && feat && dist && label && rayflag,
                 "sdn_field_encode: null pointer");
@@ -2001,6 +2010,7 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
     p.sample_depth = sample_depth; p.dists_scale = dists_scale;
     p.lin = lin_dev;
     p.u = u_dev;
+    p.ieee_div = strat_division;
     p.scales = scales_dev;
     if (int rc = set_window(p.win, window_host, n_rays, "sdn_field_encode")) return rc;
     hipLaunchKernelGGL(encode_kernel, dim3(sdn::div_up(p.n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, p);
@@ -2008,13 +2018,15 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
 }
 
 int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_dev, int32_t n_rays, int32_t max_blocks,
-                     int32_t n_points, float sample_depth, float *rand_depth, float *new_dists, int64_t *idx, sdn_stream_t stream) {
+                     int32_t n_points, float sample_depth, float *rand_depth, float *new_dists, int64_t *idx,
+                     int32_t strat_division, sdn_stream_t stream) {
     SDN_REQUIRE(depth2 && lin_dev && rand_depth && new_dists && idx, "sdn_sample_depth: null pointer");
+    SDN_REQUIRE(strat_division == 0 || strat_division == 1, "sdn_sample_depth: strat_division must be 0 (x * (1/n)) or 1 (x / n)");
     SDN_REQUIRE(n_rays > 0 && n_points >= 2, "sdn_sample_depth: need at least one ray and two stratified points");
     if (max_blocks < 1 || max_blocks > MAXM) return sdn::fail(SDN_ERR_UNSUPPORTED, "sdn_sample_depth: max_blocks must be 1..8");
     SampleParams p;
     p.depth2 = depth2; p.lin = lin_dev; p.u = u_dev; p.rand_depth = rand_depth; p.new_dists = new_dists; p.idx = idx;
-    p.R = n_rays; p.M = max_blocks; p.n_points = n_points; p.sample_depth = sample_depth;
+    p.R = n_rays; p.M = max_blocks; p.n_points = n_points; p.sample_depth = sample_depth; p.ieee_div = strat_division;
     hipLaunchKernelGGL(sample_depth_kernel, dim3(sdn::div_up(n_rays, 256)), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_sample_depth");
 }

@@ -5,8 +5,14 @@ host-computed pose), so there is NO data-path collective: RCCL (to
 backend "nccl" on ROCm) is only used once, before rendering, to broadcast the scene volume, the
 weights and the style code from rank 0.  Large tensors are sent as scatter + all_gather so that the
 root pushes a distinct 1/N slice over each of its xGMI links instead of N-1 full copies (xGMI is
-point-to-point; a flat broadcast is root-egress bound).  Works with the gloo backend on CPU tensors,
-which is how the logic is tested without GPUs.
+point-to-point; a flat broadcast is root-egress bound).
+
+Backends: "nccl" (= RCCL) with device tensors is the production path.  "gloo" is supported for CPU tensors (how the
+logic is tested without GPUs) AND for device tensors: gloo has no scatter / gather / all_gather on device memory, so
+with gloo every collective on a device tensor is staged through host memory (`_host_staged`).  That is how the GPU-side
+paths (compact-volume broadcast into device memory, sharded frames, tile-parallel frame with the real Renderer) run
+under world_size 2 on a ONE-GPU box (tests/test_dist_gpu.py); the choice depends only on (backend, device type), which is
+the same on every rank, never on a per-call try/except.
 """
 import numpy as np
 import torch
@@ -22,11 +28,48 @@ def _is_init():
     return dist.is_available() and dist.is_initialized()
 
 
-def _scatter_supported():
-    """Whether the scatter + all_gather form is used.  Decided ONCE and IDENTICALLY on every rank from the backend
-    name -- never per call with try/except around a collective: if one rank raised and fell back to broadcast while
-    the others sat in scatter, the job would hang."""
-    return dist.get_backend() in ("nccl", "gloo")
+def _host_staged(t):
+    """gloo + device tensor: the collective runs on a host copy (gloo implements scatter / gather / all_gather for CPU
+    tensors only).  A function of (backend, device type): identical on every rank."""
+    return dist.get_backend() == "gloo" and t.is_cuda
+
+
+def _scatter_supported(t):
+    """Whether the scatter + all_gather form is used for tensor `t`.  Decided IDENTICALLY on every rank from the backend
+    name and the tensor's device type -- never per call with try/except around a collective: if one rank raised and fell
+    back to broadcast while the others sat in scatter, the job would hang.  nccl: device tensors only (a CPU tensor would
+    have no implementation at all -> plain broadcast is not available either, so it is refused up front); gloo: CPU
+    tensors, device tensors through their host copies."""
+    b = dist.get_backend()
+    if b == "nccl":
+        if not t.is_cuda:
+            raise RuntimeError("the nccl (RCCL) backend moves device tensors only; got a CPU tensor")
+        return True
+    return b == "gloo"
+
+
+def all_reduce(t, op=None, group=None):
+    """dist.all_reduce that also works for device tensors under gloo (host-staged)."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _host_staged(t):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def gather(t, dst=0, group=None):
+    """List of every rank's `t` on rank `dst` (None elsewhere); device tensors under gloo are host-staged and returned on
+    `t`'s device."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    src = t.cpu() if _host_staged(t) else t
+    outs = [torch.empty_like(src) for _ in range(world)] if rank == dst else None
+    dist.gather(src, outs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [o.to(t.device) for o in outs] if src is not t else outs
 
 
 def broadcast_large(t, src=0, min_numel=1 << 20):
@@ -36,11 +79,20 @@ def broadcast_large(t, src=0, min_numel=1 << 20):
         return t
     flat = t.reshape(-1)
     n = flat.numel()
-    if n < min_numel or n % world != 0 or not t.is_contiguous() or not _scatter_supported():
+    rank = dist.get_rank()
+    if _host_staged(t):
+        # gloo + device memory: the same protocol on a (pinned) host image of the tensor, then one H2D copy
+        h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        if rank == src:
+            h.copy_(t)
+        broadcast_large(h, src, min_numel)
+        if rank != src:
+            t.copy_(h)
+        return t
+    if n < min_numel or n % world != 0 or not t.is_contiguous() or not _scatter_supported(t):
         dist.broadcast(t, src)
         return t
     chunk = n // world
-    rank = dist.get_rank()
     mine = torch.empty(chunk, dtype=t.dtype, device=t.device)
     parts = [flat[i * chunk:(i + 1) * chunk].contiguous() for i in range(world)] if rank == src else None
     dist.scatter(mine, parts, src=src)
@@ -80,8 +132,8 @@ def broadcast_tensor_dict(d, dev, src=0, verify=True):
     if verify:
         sums = torch.tensor([checksum(v) for v in out.values()], dtype=torch.int64, device=dev)
         lo, hi = sums.clone(), sums.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        all_reduce(lo, op=dist.ReduceOp.MIN)
+        all_reduce(hi, op=dist.ReduceOp.MAX)
         if not torch.equal(lo, hi):
             raise RuntimeError("broadcast integrity check failed: checksums differ across ranks")
     return out
@@ -163,7 +215,7 @@ def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode=
     red = torch.cat([hd["sky_sum"].to(torch.float64).reshape(64),
                      torch.tensor([float(hd["sky_cnt"])], dtype=torch.float64, device=hd["sky_sum"].device)])
     if world > 1:
-        dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
+        all_reduce(red, op=dist.ReduceOp.SUM, group=group)
     sky_avg = (red[:64] / red[64]).to(torch.float32).reshape(1, 64)
     img = renderer.band_finish(hd, sky_avg, num_samples)
     if world == 1:
@@ -171,8 +223,27 @@ def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode=
     hmax = max(b[1] - b[0] for b in bands)
     pad = torch.zeros((1, 3, hmax, W), dtype=img.dtype, device=img.device)
     pad[:, :, :img.shape[2]] = img
-    outs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
-    dist.gather(pad, outs, dst=0, group=group)
+    outs = gather(pad, dst=0, group=group)
     if rank != 0:
         return None
     return torch.cat([o[:, :, :b[1] - b[0]] for o, b in zip(outs, bands)], dim=2)
+
+
+def agree_cnn_precision(renderer, pose, resolution_hw, num_samples, group=None):
+    """The render CNN's per-style precision gate (Renderer.mfma_cnn) evaluated ONCE FOR THE JOB: every rank renders the same
+    frame (`pose`; renders are bit-reproducible, so every rank measures the same 1-term vs 3-term difference), the
+    measured differences are reduced with MAX, and every rank adopts that one decision -- bands of one frame, or frames of
+    one trajectory, never mix the two CNN precisions.  No-op when the precision is set explicitly.  Returns the record."""
+    if getattr(renderer, "cnn_terms3x3", None) is not None or "SDN_CNN_TERMS" in __import__("os").environ:
+        return None
+    renderer.cnn_calibration = None
+    renderer.render_frame(pose, resolution_hw, num_samples, mode="fused")
+    cal = dict(renderer.cnn_calibration)
+    if _is_init() and dist.get_world_size(group) > 1:
+        d = torch.tensor([cal["max_abs_diff_1term_vs_3term"]], dtype=torch.float64, device=renderer.dev)
+        all_reduce(d, op=dist.ReduceOp.MAX, group=group)
+        cal["max_abs_diff_1term_vs_3term"] = float(d.item())
+        cal["terms3x3"] = 1 if cal["max_abs_diff_1term_vs_3term"] <= cal["bound"] else 3
+        cal["agreed_over_ranks"] = dist.get_world_size(group)
+    renderer.cnn_calibration = cal
+    return cal

@@ -114,11 +114,12 @@ def _buffers(R, n_rays, ns, slot=0):
     return cache[key]
 
 
-def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None, window=None, ray0=0, n_rays=None):
+def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None, window=None, ray0=0, n_rays=None, division="reciprocal"):
     """Sample placement + hash-grid lookup for n_rays rays of the ray arrays vid / d2 / rd: all of them (window None), or
     rays ray0 .. ray0 + n_rays - 1 of `window` (a Window over the frame-wide arrays).
     u: None = deterministic sampling (inference); f32 [n_rays, ns + 1] uniform randoms (the caller's
-    torch.rand(..., ns + 1) draw, mc_utils.py:121) = the training-time stratified sampling."""
+    torch.rand(..., ns + 1) draw, mc_utils.py:121) = the training-time stratified sampling; `division` as in
+    ops.sample_depth_batched ("reciprocal": the reference on a CUDA tensor, "ieee": on a CPU tensor)."""
     sc = R._fused_scene or prepare_scene(R)
     if window is None:
         window = Window(vid.shape[0])
@@ -140,7 +141,8 @@ def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None, window=None, ray0=0, n
                                      lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M, ns,
                                      R.sample_depth, R.dists_scale,
                                      buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                     buf["rayflag"].data_ptr(), window.host(ray0), _stream(R.dev))
+                                     buf["rayflag"].data_ptr(), window.host(ray0), {"reciprocal": 0, "ieee": 1}[division],
+                                     _stream(R.dev))
     capi.check(rc, "sdn_field_encode")
     return buf
 
@@ -172,6 +174,9 @@ def _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, passes=None, wi
     ticket counter (one per renderer: launches of one renderer are serialized on its stream) instead of a static stride."""
     ct, eps = precision_profile(R)
     assert sky_c.is_contiguous() and sky_avg.is_contiguous() and sky_avg.numel() == 64 and sky_avg.dtype == torch.float32
+    # both are dereferenced by the kernel: a host tensor here would be a wild device pointer (memory fault), not an error code
+    if not (sky_c.is_cuda and sky_avg.is_cuda and sky_c.device == R.dev == sky_avg.device and net_out.device == R.dev):
+        raise ValueError(f"sky_c / sky_avg / net_out must live on {R.dev} (got {sky_c.device}, {sky_avg.device}, {net_out.device})")
     if window is None:
         window = Window(sky_c.shape[0])
     if "ticket" not in st:
@@ -201,7 +206,7 @@ def single_chunk(n_rays, ns):
     return n_rays * _per_ray_feat_bytes(ns) <= FEATURE_BUFFER_BYTES
 
 
-def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None, window=None):
+def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None, window=None, division="reciprocal"):
     """net_out [n,64] for the rays of `window` (default: all) of the intersections vid [n_src,M] / d2 [2,n_src,M] /
     raydirs rd [n_src,3], sky features sky_c [n_src,64] and their frame mean sky_avg [64].
     Rays are independent, so very large frames (4K x 40 samples = 174 GB of features) go through in ray chunks that
@@ -211,13 +216,13 @@ def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None
         window = Window(vid.shape[0])
     n_rays = window.n_rays
     vid, d2, rd, sky_c = vid.contiguous(), d2.contiguous(), rd.contiguous(), sky_c.contiguous()
-    sky_avg = sky_avg.reshape(-1).to(torch.float32).contiguous()
+    sky_avg = torch.as_tensor(sky_avg).reshape(-1).to(device=R.dev, dtype=torch.float32).contiguous()   # (a host mean is accepted)
     net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
     chunk = max(32, (FEATURE_BUFFER_BYTES // _per_ray_feat_bytes(ns)) // 32 * 32)     # whole 32-ray groups
     for r0 in range(0, n_rays, chunk):
         n = min(n_rays, r0 + chunk) - r0
         uc = u[r0:r0 + n].contiguous() if u is not None else None
-        buf = encode(R, vid, d2, rd, cam_ori, ns, u=uc, window=window, ray0=r0, n_rays=n)
+        buf = encode(R, vid, d2, rd, cam_ori, ns, u=uc, window=window, ray0=r0, n_rays=n, division=division)
         _launch_mlp(R, buf, st, sky_c, sky_avg, net_out[r0:r0 + n], n, ns, passes[r0 // 32:] if passes is not None else None,
                     window=window, ray0=r0)
     return net_out

@@ -95,18 +95,31 @@ def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f
     return [voxel_id, depth2, raydirs]
 
 
-def sample_depth_batched(depth2, nsamples, deterministic=False, use_box_boundaries=True, sample_depth=4, rand=None):
-    """mc_utils.sample_depth_batched (imaginaire/model_utils/gancraft/mc_utils.py:82-151), same signature and return
-    values: depth2 [N,2,H,W,M,1] -> (rand_depth [N,H,W,nsamples-1,1], new_dists likewise, idx int64 likewise).
-    `rand` (not in the reference signature): the uniform randoms of the stochastic branch, [N,H,W,nsamples,1]; by default
-    drawn with torch.rand exactly as the reference does (:121), so a seeded call reproduces the reference's samples.
-    use_box_boundaries=True (unused by SceneDreamer's configs, scenedreamer_train.yaml:121) is not implemented."""
+def sample_depth_batched(depth2, nsamples, deterministic=False, use_box_boundaries=True, sample_depth=4, rand=None,
+                         division="reciprocal", boundary_rand=None):
+    """mc_utils.sample_depth_batched (imaginaire/model_utils/gancraft/mc_utils.py:82-151), same signature, defaults and
+    return values: depth2 [N,2,H,W,M,1] -> (rand_depth [N,H,W,K,1], new_dists likewise, idx int64 likewise), K = nsamples - 1
+    (use_box_boundaries=False: SceneDreamer's configs, scenedreamer.py:346-348) or nsamples + M (True).
+
+    Not in the reference signature:
+    rand: the uniform randoms of the stochastic branch, [N,H,W,nsamples,1]; by default drawn with torch.rand exactly as the
+      reference does (:121), so a seeded call consumes the generator like the reference's call.
+    division: how `rand_samples / nsamples` (:123, tensor / Python scalar) is evaluated.  "reciprocal" (default): as PyTorch
+      evaluates it on a CUDA tensor -- the reference's GPU path -- a multiplication by the float32 reciprocal
+      (BinaryDivTrueKernel.cu, CPU-scalar fast path); "ieee": as on a CPU tensor, a true division -- what the goldens recorded
+      from the reference's CPU run contain.  At most 1 ulp apart, and only when nsamples is not a power of two.
+    boundary_rand: the filler draw of the use_box_boundaries branch (:111, torch.rand_like(accu_depth)), [N,H,W,M,1].
+
+    use_box_boundaries=False runs in one HIP kernel (sdn_sample_depth).  use_box_boundaries=True (GANcraft's option; no
+    SceneDreamer config uses it, scenedreamer_train.yaml:121) needs a per-ray sort of nsamples + M + 1 positions and is
+    composed from PyTorch ops on the device, in the reference's order of operations and of generator draws."""
     _require(isinstance(depth2, torch.Tensor) and depth2.is_cuda and depth2.dtype == torch.float32, "depth2 must be a CUDA float32 tensor")
     _require(depth2.dim() == 6 and depth2.shape[1] == 2 and depth2.shape[-1] == 1, "depth2 must be [N,2,H,W,M,1]")
-    if use_box_boundaries:
-        raise NotImplementedError("sample_depth_batched(use_box_boundaries=True)")
+    _require(division in ("reciprocal", "ieee"), "division must be 'reciprocal' or 'ieee'")
     N, _, H, W, M, _ = depth2.shape
     dev = depth2.device
+    if use_box_boundaries:
+        return _sample_depth_with_boundaries(depth2, nsamples, deterministic, sample_depth, rand, division, boundary_rand)
     R = N * H * W
     d2 = depth2.permute(1, 0, 2, 3, 4, 5).reshape(2, R, M).contiguous()
     if deterministic:
@@ -123,9 +136,40 @@ def sample_depth_batched(depth2, nsamples, deterministic=False, use_box_boundari
         idx = torch.empty((R, nsamples - 1), dtype=torch.int64, device=dev)
         capi.check(capi.lib().sdn_sample_depth(d2.data_ptr(), lin.data_ptr(), u.data_ptr() if u is not None else None, R, M,
                                                nsamples, float(sample_depth), depth.data_ptr(), dists.data_ptr(),
-                                               idx.data_ptr(), _stream(depth2)), "sdn_sample_depth")
+                                               idx.data_ptr(), 1 if division == "ieee" else 0, _stream(depth2)),
+                   "sdn_sample_depth")
     shape = (N, H, W, nsamples - 1, 1)
     return depth.view(shape), dists.view(shape), idx.view(shape)
+
+
+def _sample_depth_with_boundaries(depth2, nsamples, deterministic, sample_depth, rand, division, boundary_rand):
+    """The use_box_boundaries=True form of mc_utils.sample_depth_batched (:108-114, :127-131): the in-range box exits join
+    the samples (out-of-range ones are replaced by uniform fillers), plus a sample at depth 0, before the sort."""
+    N, _, H, W, M, _ = depth2.shape
+    dev = depth2.device
+    t, t2 = depth2[:, 0], depth2[:, 1]
+    d = torch.nan_to_num(t2 - t, nan=0.0)
+    accu = torch.cumsum(d, dim=-2)
+    total = accu[..., -1:, :].clamp(max=sample_depth)
+    if boundary_rand is None:
+        boundary_rand = torch.rand_like(accu)                           # drawn before the stratified randoms, :111 / :121
+    bad = (accu > sample_depth) | (d == 0)
+    bnd = torch.where(bad, boundary_rand * total, accu)
+    if deterministic:
+        s = torch.linspace(0, 1, nsamples + 2)[1:-1].to(dev).view(1, 1, 1, nsamples, 1).expand(N, H, W, nsamples, 1)
+    else:
+        if rand is None:
+            rand = torch.rand([N, H, W, nsamples, 1], dtype=depth2.dtype, device=dev)
+        s = (rand * (1.0 / nsamples) if division == "reciprocal" else rand / torch.tensor(float(nsamples), device=dev)) \
+            + torch.linspace(0, 1, nsamples + 1, device=dev)[:-1].view(1, 1, 1, nsamples, 1)
+    s = torch.cat([s * total, bnd, torch.zeros([N, H, W, 1, 1], dtype=depth2.dtype, device=dev)], dim=-2)
+    s, _ = torch.sort(s, dim=-2)
+    mid = (s[..., 1:, :] + s[..., :-1, :]) / 2
+    new_dists = s[..., 1:, :] - s[..., :-1, :]
+    idx = (mid.unsqueeze(-3) > accu.unsqueeze(-2)).sum(dim=-3)
+    gaps = torch.cumsum(t[..., 1:, :] - t2[..., :-1, :], dim=-2)
+    heads = torch.cat([t[..., :1, :], gaps + t[..., :1, :]], dim=-2)
+    return torch.gather(heads, -2, idx) + mid, new_dists, idx
 
 
 def _pe_sizes(t, dim):

@@ -44,6 +44,8 @@ class Renderer:
     def __init__(self, weights, scene, device="cuda", num_blocks_early_stop=6, sample_depth=3.0, dists_scale=0.25,
                  pad=30):
         self.dev = torch.device(device)
+        if self.dev.type == "cuda" and self.dev.index is None:      # "cuda" -> "cuda:<current>": tensor.device carries the index
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self.w = {k: (v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))).to(self.dev)
                   for k, v in weights.items()}
         lut = load_label_lut()
@@ -127,6 +129,7 @@ class Renderer:
             self.cnn_adapt = F.linear(z, w["denoiser.fc_z_cond.weight"], w["denoiser.fc_z_cond.bias"])
         self._fused_style = None
         self._fused_sky = None
+        self.cnn_calibration = None      # the FiLM vectors changed: the render CNN's precision gate is re-evaluated
 
     # ------------------------------------------------------------------ stages
     def cast_rays(self, pose, resolution_hw):
@@ -225,21 +228,65 @@ class Renderer:
     # ------------------------------------------------------------------ measurement
     def set_precision(self, cnn_terms3x3=None, colour_terms=None, term_eps=None):
         """Precision profile of the MFMA kernels (None = the default of the environment / library):
-        cnn_terms3x3: f16 product terms of the four 3x3 convolutions, 1 (default) or 3 (cnn.py);
+        cnn_terms3x3: f16 product terms of the four 3x3 convolutions: 1, 3, or None = "auto" (1 if it passes the per-style
+                      calibration against the 3-term evaluation, else 3 -- see mfma_cnn);
         colour_terms: products of the colour layers fc_5 / fc_6: 6 (default: f16 + fp6 corrections), 3 or 2 (fused.precision_profile);
         term_eps: early ray termination threshold on the transmittance, 0 = off (default)."""
         self.cnn_terms3x3, self.colour_terms, self.term_eps = cnn_terms3x3, colour_terms, term_eps
-        self._mfma_cnn = None
+        self._mfma_cnns = {}
+        self.cnn_calibration = None
+
+    def mfma_cnn(self, net_out):
+        """The MFMA render CNN (cnn.MfmaCNN) for the current precision profile.
+
+        The four 3x3 convolutions can run as ONE f16 product (operands rounded to nearest: a third of the MFMAs, 3.4 ms
+        instead of 7.3 ms per 960x540 frame) or as the 3-term f16 split (agrees with the fp32 CNN to < 2e-5).  The
+        1-term form is LOSSY -- its error grows with the activations' magnitude, i.e. it depends on the loaded weights
+        and the style -- so it is not a blind default: with cnn_terms3x3 = None ("auto") the first net_out presented
+        after a style change is pushed through both forms, and the 1-term kernels are used only if their image differs
+        from the 3-term image by at most CNN_AUTO_BOUND (max abs) on that frame; otherwise the 3-term kernels are.
+        The decision and the measured difference are kept in `cnn_calibration` (bench.py prints them).  An explicit
+        cnn_terms3x3 (set_precision, or SDN_CNN_TERMS in the environment) bypasses the gate."""
+        from .cnn import MfmaCNN
+        cache = self.__dict__.setdefault("_mfma_cnns", {})
+
+        def get(t):
+            if t not in cache:
+                cache[t] = MfmaCNN(self, t)
+            return cache[t]
+
+        want = getattr(self, "cnn_terms3x3", None)
+        if want is None and "SDN_CNN_TERMS" in os.environ:
+            want = int(os.environ["SDN_CNN_TERMS"])
+        if want is not None:
+            return get(want)
+        cal = getattr(self, "cnn_calibration", None)
+        if cal is None:
+            bound = float(getattr(self, "cnn_auto_bound", None) or CNN_AUTO_BOUND)
+            with torch.no_grad():
+                d = float((get(3)(net_out) - get(1)(net_out)).abs().max())
+            cal = self.cnn_calibration = {"terms3x3": 1 if d <= bound else 3, "max_abs_diff_1term_vs_3term": d, "bound": bound,
+                                          "frame": f"first frame of the style, {net_out.shape[1]}x{net_out.shape[2]} px"}
+            cache[4 - cal["terms3x3"]]._planes.clear()      # the form not chosen keeps its packed weights, not its planes
+        return get(cal["terms3x3"])
 
     def compute_dtype(self, mode):
         if mode == "unfused":
             return "f32"
         from . import fused
         ct, _ = fused.precision_profile(self)
-        t3 = getattr(self, "cnn_terms3x3", None) or int(os.environ.get("SDN_CNN_TERMS", "1"))
+        cal = getattr(self, "cnn_calibration", None)
+        t3 = getattr(self, "cnn_terms3x3", None) or (int(os.environ["SDN_CNN_TERMS"]) if "SDN_CNN_TERMS" in os.environ else None)
+        if t3 is None:
+            t3 = (f"{cal['terms3x3']}-term (auto: 1-term vs 3-term image differed by {cal['max_abs_diff_1term_vs_3term']:.1e} <= "
+                  f"{cal['bound']:.0e} on the style's first frame)" if cal and cal["terms3x3"] == 1 else
+                  f"3-term (auto: the 1-term form differed by {cal['max_abs_diff_1term_vs_3term']:.1e} > {cal['bound']:.0e})" if cal
+                  else "auto (1-term if within 5e-4 of the 3-term image, not yet calibrated)")
+        else:
+            t3 = f"{t3}-term (set explicitly)"
         return (f"f32 (hash grid) + f16 MFMA with f32 accumulate: field/sky MLP 3-term split"
                 f"{' (colour layers 2-term)' if ct == 2 else ' (colour layers: f16 Whi.Xhi + MX-fp6 corrections)' if ct == 6 else ''}"
-                f", render CNN 1x1 3-term / 3x3 {t3}-term")
+                f", render CNN 1x1 3-term / 3x3 {t3}")
 
     def measure_roofline(self, pose, resolution_hw, num_samples, mode, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0):
         """Roofline records, timed with events on the launch stream (PyTorch's current stream).
@@ -265,9 +312,15 @@ class Renderer:
                                                               feats, B, 5, 8, self.grid_L, self.grid_S, 16, False, dummy,
                                                               0, False))
                 achieved = B * 16916 / (ms * 1e-3) / 1e9
-                grid = {"bound": "hbm", "kernel": "grid_fwd_quad_kernel<5,8> (drop-in GridEncoder.forward, 32-corner 5-D gather)", "achieved": achieved,
-                        "peak": hbm_peak_gbps, "unit": "GB/s", "frac": achieved / hbm_peak_gbps, "traffic": None,
-                        "samples_per_launch": B, "algorithmic_bytes_per_sample": 16916, "avg_launch_ms": ms}
+                # 32 corner rows x 32 B x 16 levels per sample really are requested, but from a 268 MB table whose coarse levels
+                # stay in L2 / Infinity Cache: the rate is an on-die gather rate, bounded by the aggregate L2 bandwidth -- not
+                # by HBM (dividing it by the HBM peak gave a "fraction" above 1)
+                grid = {"bound": "l2", "kernel": "grid_fwd_quad_kernel<5,8> (drop-in GridEncoder.forward, 32-corner 5-D gather)", "achieved": achieved,
+                        "peak": L2_PEAK_GBPS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBPS, "traffic": None,
+                        "effective_over_hbm_peak": achieved / hbm_peak_gbps,
+                        "samples_per_launch": B, "algorithmic_bytes_per_sample": 16916, "avg_launch_ms": ms,
+                        "note": "achieved = samples x 16 916 B (SURVEY 8(d), un-fused) / launch time: L2-level gather rate; peak = "
+                                "aggregate L2 bandwidth (MI355X_MICROARCH.md: 34.5 TB/s); DRAM traffic not profiled for this kernel"}
                 return grid, grid
             from . import fused
             vid, d2, rd = vid.view(R, self.M), d2.view(2, R, self.M), rd.view(R, 3)
@@ -396,10 +449,7 @@ class Renderer:
             if cnn_mode is None:
                 cnn_mode = "mfma" if mode == "fused" else "torch"
             if cnn_mode == "mfma":
-                if getattr(self, "_mfma_cnn", None) is None:
-                    from .cnn import MfmaCNN
-                    self._mfma_cnn = MfmaCNN(self, getattr(self, "cnn_terms3x3", None))
-                img = self._mfma_cnn(net_out)
+                img = self.mfma_cnn(net_out)(net_out)
             else:
                 img = self.render_cnn(net_out)
             p = self.pad // 2
@@ -470,10 +520,7 @@ class Renderer:
             if cnn_mode is None:
                 cnn_mode = "mfma" if mode == "fused" else "torch"
             if cnn_mode == "mfma":
-                if getattr(self, "_mfma_cnn", None) is None:
-                    from .cnn import MfmaCNN
-                    self._mfma_cnn = MfmaCNN(self, getattr(self, "cnn_terms3x3", None))
-                img = self._mfma_cnn(net_out)
+                img = self.mfma_cnn(net_out)(net_out)
             else:
                 img = self.render_cnn(net_out)
             if crop:
@@ -556,13 +603,11 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
             if probe is not None:
                 e1.record(main)
                 probe.setdefault("mlp_kernel", []).append((e0, e1))
-            if getattr(self, "_mfma_cnn", None) is None:
-                from .cnn import MfmaCNN
-                self._mfma_cnn = MfmaCNN(self, getattr(self, "cnn_terms3x3", None))
+            cnn = self.mfma_cnn(net_out)         # (first frame of a style: calibrates the 3x3 precision, see mfma_cnn)
             if probe is not None:
                 c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 c0.record(main)
-            img = self._mfma_cnn(net_out)
+            img = cnn(net_out)
             if probe is not None:
                 c1.record(main)
                 probe.setdefault("render_cnn", []).append((c0, c1))
@@ -572,28 +617,39 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
 
 Renderer.render_frames = _render_frames
 
+CNN_AUTO_BOUND = 5e-4   # mfma_cnn: largest image difference (max abs) at which the 1-term 3x3 convolutions are accepted
 CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (conv2a, conv2b, conv3a, conv3b)
 
 
 L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md: 4 MiB per XCD, ~34.5 TB/s aggregate
-PMC_PROFILE = "r02_pmc_traffic.json"
+PMC_PROFILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
 
 
 def _profiled_traffic():
-    """(HBM bytes per launch by kernel, source label) from the committed PMC profile: bench.py cannot run rocprofv3 on
-    itself, so `traffic` in the roofline records is NOT measured in the bench process -- the label says so."""
+    """(HBM bytes per launch by kernel, source label) from the newest committed PMC profile: bench.py cannot run rocprofv3 on
+    itself, so `traffic` in the roofline records is NOT measured in the bench process -- the label says so.  A profile is
+    used only if it was taken on THESE kernel sources: tools/pmc_traffic.py stores the digest of csrc/*.hip + the header
+    (build._digest(), the same value as lib/libsdnative.stamp) and a profile whose digest differs from the current
+    sources' -- or that predates the digest field -- yields no traffic figure and a label that says why."""
     import json
+    from . import build
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for name in (PMC_PROFILE, "r01_pmc_traffic.json"):
+    cur = build._digest()
+    why = None
+    for name in PMC_PROFILES:
         try:
             with open(os.path.join(root, "profiles", name)) as f:
                 d = json.load(f)
-            return ({k: v["traffic"] for k, v in d["per_launch_bytes"].items()},
-                    f"profiles/{name} (rocprofv3 --pmc passes of tools/frame_once.py, build {d.get('commit', 'unrecorded')}; "
-                    f"not measured in this run)")
+            per = {k: v["traffic"] for k, v in d["per_launch_bytes"].items()}
         except (OSError, KeyError, ValueError):
             continue
-    return {}, None
+        if d.get("csrc_digest") != cur:
+            why = why or (f"profiles/{name} is STALE (taken at build {d.get('commit', 'unrecorded')}, kernel-source digest "
+                          f"{str(d.get('csrc_digest'))[:12]} != current {cur[:12]}): no traffic figure reported")
+            continue
+        return (per, f"profiles/{name} (rocprofv3 --pmc passes of tools/frame_once.py, build {d.get('commit', 'unrecorded')}, "
+                     f"kernel-source digest {cur[:12]} = this build; not measured in this run)")
+    return {}, why
 
 
 def _time_ms(fn, reps=5):

@@ -15,12 +15,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "needs_reference: needs /root/reference (build container only)")
+    config.addinivalue_line("markers", "needs_reference: needs the reference's Python tree: /root/reference (build container) or the "
+                            "staged archive oracle/_ref/pytree.zip (GPU box)")
 
 
 def pytest_collection_modifyitems(config, items):
-    have_ref = os.path.isdir("/root/reference/imaginaire")
-    skip_ref = pytest.mark.skip(reason="/root/reference not present on this machine")
+    have_ref = os.path.isdir("/root/reference/imaginaire") or os.path.exists(os.path.join(ROOT, "oracle", "_ref", "pytree.zip"))
+    skip_ref = pytest.mark.skip(reason="neither /root/reference nor oracle/_ref/pytree.zip on this machine")
     for item in items:
         if "needs_reference" in item.keywords and not have_ref:
             item.add_marker(skip_ref)

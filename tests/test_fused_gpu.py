@@ -157,8 +157,9 @@ def test_sample_depth_op_matches_reference_golden():
     g = golden("stochastic_sampling.npz")
     d2 = torch.from_numpy(g["depth2"]).cuda()
     for ns in (13, 25):
+        # (the goldens were recorded from the reference's CPU run: rand / nsamples as an IEEE division)
         rd, nd, idx = ops.sample_depth_batched(d2, ns, deterministic=False, use_box_boundaries=False, sample_depth=3,
-                                               rand=torch.from_numpy(g[f"u{ns}"]).cuda())
+                                               rand=torch.from_numpy(g[f"u{ns}"]).cuda(), division="ieee")
         assert rd.shape == g[f"depth{ns}"].shape and idx.dtype == torch.int64
         np.testing.assert_array_equal(idx.cpu().numpy().astype(np.int8), g[f"idx{ns}"])
         np.testing.assert_array_equal(bits(rd.cpu().numpy()), bits(g[f"depth{ns}"]))
@@ -174,8 +175,63 @@ def test_sample_depth_op_matches_reference_golden():
     u = torch.rand([1, d2.shape[2], d2.shape[3], 13, 1], dtype=torch.float32, device="cuda")
     b = ops.sample_depth_batched(d2, 13, deterministic=False, use_box_boundaries=False, sample_depth=3, rand=u)
     assert torch.equal(a[2], b[2]) and torch.equal(a[0].nan_to_num(-1), b[0].nan_to_num(-1))
-    with pytest.raises(NotImplementedError):
-        ops.sample_depth_batched(d2, 13, deterministic=True, use_box_boundaries=True)
+
+
+def test_stratified_positions_follow_the_gpu_reference_division():
+    """`rand_samples / nsamples` (mc_utils.py:123) on a CUDA tensor is a multiplication by the float32 reciprocal in PyTorch,
+    on a CPU tensor an IEEE division.  The op's default (division="reciprocal") must reproduce what the reference's lines
+    give when they run on THIS GPU; rays with a single box are used so that the cumulative box depth -- where the CUDA
+    and CPU cumsum kernels differ too -- is the same number either way: new_dists then has to agree bit for bit."""
+    from conftest import bits
+    from scenedreamer_amd import ops
+    torch.manual_seed(11)
+    n, M = 4096, 6
+    t = torch.full((1, 1, n, M, 1), float("nan"), device="cuda")
+    t2 = t.clone()
+    t[..., 0, :] = 1 + 4 * torch.rand(1, 1, n, 1, device="cuda")
+    t2[..., 0, :] = t[..., 0, :] + 0.05 + 3.5 * torch.rand(1, 1, n, 1, device="cuda")
+    d2 = torch.stack([t, t2], dim=1)
+    differ = 0
+    for ns in (13, 25, 41):
+        u = torch.rand([1, 1, n, ns, 1], device="cuda")
+        total = (t2[..., :1, :] - t[..., :1, :]).clamp(max=3.0)
+        s = u / ns                                                              # the reference's expression, on the GPU
+        s = (s + torch.linspace(0, 1, ns + 1, device="cuda")[:-1].view(1, 1, 1, ns, 1)) * total
+        want = s[..., 1:, :] - s[..., :-1, :]
+        got = ops.sample_depth_batched(d2, ns, deterministic=False, use_box_boundaries=False, sample_depth=3, rand=u)[1]
+        np.testing.assert_array_equal(bits(got.cpu().numpy()), bits(want.cpu().numpy()))
+        ieee = ops.sample_depth_batched(d2, ns, deterministic=False, use_box_boundaries=False, sample_depth=3, rand=u,
+                                        division="ieee")[1]
+        differ += int((ieee != got).sum())
+    assert differ > 0       # the two conventions are distinguishable on this input, so the test above means something
+
+
+@pytest.mark.needs_reference
+def test_sample_depth_with_box_boundaries_matches_reference():
+    """use_box_boundaries=True (the reference signature's default) against the UNMODIFIED mc_utils.sample_depth_batched run
+    on the CPU with the same two random draws (torch.rand_like / torch.rand are handed the tensors)."""
+    from unittest import mock
+
+    from oracle import ref_harness as RH
+    from scenedreamer_amd import ops
+    RH.install("oracle")
+    from imaginaire.model_utils.gancraft import mc_utils
+    g = golden("stochastic_sampling.npz")
+    d2 = torch.from_numpy(g["depth2"])
+    N, _, H, W, M, _ = d2.shape
+    torch.manual_seed(3)
+    for ns, det in ((13, False), (25, False), (13, True)):
+        ub, u = torch.rand(N, H, W, M, 1), torch.rand(N, H, W, ns, 1)
+        with mock.patch.object(torch, "rand_like", lambda x: ub.clone()), mock.patch.object(torch, "rand", lambda *a, **k: u.clone()):
+            ref = mc_utils.sample_depth_batched(d2.clone(), ns, deterministic=det, use_box_boundaries=True, sample_depth=3)
+        got = ops.sample_depth_batched(d2.cuda(), ns, deterministic=det, use_box_boundaries=True, sample_depth=3,
+                                       rand=u.cuda(), boundary_rand=ub.cuda(), division="ieee")
+        assert got[0].shape == ref[0].shape == (N, H, W, ns + M, 1) and got[2].dtype == torch.int64
+        same = (got[2].cpu() == ref[2])
+        assert float(same.float().mean()) > 0.999          # (cumsum: float scan on the GPU, double accumulation on the CPU)
+        np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].numpy(), rtol=0, atol=2e-6, equal_nan=True)
+        a, b = got[0].cpu()[same], ref[0][same]
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=0, atol=2e-5, equal_nan=True)
 
 
 def test_fused_encode_with_stochastic_sampling(renderer, weights_full, lut):

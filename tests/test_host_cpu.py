@@ -261,6 +261,29 @@ def test_mp4_writer_roundtrip(tmp_path):
     assert raw[4:8] == b"ftyp" and b"moov" in raw and b"co64" in raw
 
 
+def test_mp4_writer_strided_and_late_indices_stay_bounded(tmp_path):
+    """A sharded rank submits GLOBAL frame ids (f, f + N, ...): the video thread must keep writing (bounded reorder buffer)
+    instead of holding every frame until close(); a late index is still written."""
+    import time
+
+    from scenedreamer_amd.mp4 import read_frames
+    from scenedreamer_amd.output import FrameWriter
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 32), torch.linspace(-1, 1, 48), indexing="ij")
+    frames = [torch.stack([torch.sin(3 * xx + k), torch.cos(2 * yy - k), xx * yy])[None] for k in range(24)]
+    w = FrameWriter(None, video_path=str(tmp_path / "out.mp4"), fps=10, depth=4)
+    order = [8 * i + 3 for i in range(20)] + [2, 500, 499, 501]
+    for i, idx in enumerate(order):
+        w.submit(frames[i], idx)
+    deadline = time.time() + 20
+    while len(w.video.sizes) < len(order) - 5 and time.time() < deadline:
+        time.sleep(0.05)
+    written_before_close = len(w.video.sizes)
+    w.close()
+    fps, got = read_frames(str(tmp_path / "out.mp4"))
+    assert len(got) == len(order)
+    assert written_before_close >= len(order) - 5, written_before_close     # not deferred to close()
+
+
 def test_hazard_checker_finds_planted_hazards():
     """The checker itself: a rotated loop whose text order is not its execution order (the shape hipcc gives cnn.hip's
     k loop).  Clean as written; with the loop's wait weakened, or with a read landing in a fragment that is still pending,
@@ -295,3 +318,20 @@ def test_hazard_checker_finds_planted_hazards():
     assert any("touches a pending register" in why for _, _, why in problems)
     _, problems = chk.check_kernel("conv_kernel_test", kernel(0, "v[8:11]"))   # lands in a fragment whose read is in flight
     assert any("overwrites a pending destination" in why for _, _, why in problems)
+
+
+def test_scene_maps_written_like_the_reference(tmp_path, scene256):
+    """semantic_map.png / height_map.png (scenedreamer.py:532-545, :562-563): class colours by argmax of the one-hot map,
+    height through write_img's uint8 mapping."""
+    from PIL import Image
+    from scenedreamer_amd.output import BIOME_COLORS, write_scene_maps
+    sem, height = write_scene_maps(str(tmp_path), scene256)
+    cls = torch.argmax(scene256.current_semantic_map, dim=1)[0].numpy()
+    S = cls.shape[0]
+    assert sem.shape == (S, S, 3) and height.shape == (S, S) and len(BIOME_COLORS) == scene256.current_semantic_map.shape[1] == 11
+    want = np.asarray(BIOME_COLORS, np.int32)[cls]
+    assert np.abs(sem.astype(np.int32) - want).max() <= 1            # the reference's float round trip truncates: off by <= 1
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "semantic_map.png")), sem)
+    np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "height_map.png")), height)
+    h = scene256.current_height_map[0, 0].numpy()
+    np.testing.assert_array_equal(height, ((h * 0.5 + 0.5) * 255).astype(np.uint8))

@@ -129,6 +129,38 @@ def test_mfma_cnn_matches_torch_cnn(renderer, terms3x3, bound):
         assert got.shape == ref.shape and err.max().item() < bound, f"max abs err {err.max().item():.3e}"
 
 
+def test_cnn_precision_gate_is_measured_per_style(renderer, scene256):
+    """cnn_terms3x3 = None ("auto"): the lossy 1-term 3x3 convolutions are used only when the first frame of the style shows
+    them within CNN_AUTO_BOUND of the 3-term image; otherwise the 3-term kernels run.  A new style re-opens the gate."""
+    from scenedreamer_amd import camera, synth
+    from scenedreamer_amd.renderer import CNN_AUTO_BOUND
+    pose = camera.eval_camera_poses(scene256, maxstep=8)[5]
+    hw = (64, 88)
+    try:
+        renderer.set_precision()
+        auto = renderer.render_frame(pose, hw, 12, mode="fused")
+        cal = renderer.cnn_calibration
+        assert cal["terms3x3"] == 1 and 0 < cal["max_abs_diff_1term_vs_3term"] <= CNN_AUTO_BOUND == cal["bound"]
+        assert "1-term (auto" in renderer.compute_dtype("fused")
+        renderer.set_precision(cnn_terms3x3=1)
+        assert torch.equal(auto, renderer.render_frame(pose, hw, 12, mode="fused")) and renderer.cnn_calibration is None
+        renderer.set_precision(cnn_terms3x3=3)
+        three = renderer.render_frame(pose, hw, 12, mode="fused")
+        renderer.set_precision()
+        renderer.cnn_auto_bound = 1e-7                    # a bound the 1-term form cannot meet: the gate must close
+        got = renderer.render_frame(pose, hw, 12, mode="fused")
+        assert renderer.cnn_calibration["terms3x3"] == 3 and torch.equal(got, three)
+        assert "3-term (auto" in renderer.compute_dtype("fused")
+        renderer.cnn_auto_bound = None
+        renderer.set_style(synth.make_style(8888))        # style change -> calibration dropped, evaluated again on the next frame
+        assert renderer.cnn_calibration is None
+        renderer.render_frame(pose, hw, 12, mode="fused")
+        assert renderer.cnn_calibration["terms3x3"] == 1
+    finally:
+        renderer.cnn_auto_bound = None
+        renderer.set_precision()
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_row_bands_reproduce_the_full_frame(renderer, scene256, mode):
     """Tile-parallel path on one GPU: three row bands rendered separately (global sky mean from the summed band

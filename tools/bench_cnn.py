@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 scene = synth.make_scene(256, 3407, device=dev)
 R = Renderer(synth.make_weights(0, grid_log2_hashmap=10), scene, dev)
 R.set_style(synth.make_style(8888))
-cnn = MfmaCNN(R)
+cnn = MfmaCNN(R, int(os.environ.get("SDN_CNN_TERMS", "1")))
 H, W = 570, 990
 x = torch.rand(1, H, W, 64, device=dev) * 2 - 1
 buf = cnn._buffers(H, W)

@@ -21,7 +21,7 @@ Hp, Wp = n1.shape[1:3]
 o = 11
 x_full = n1
 x_min = n1[:, o:Hp - o, o:Wp - o].contiguous()
-cnn = MfmaCNN(R)
+cnn = MfmaCNN(R, int(os.environ.get("SDN_CNN_TERMS", "1")))
 i_full = cnn(x_full)[:, :, 15:-15, 15:-15]
 i_min = cnn(x_min)[:, :, 4:-4, 4:-4]
 print("cnn-only diff", float((i_full - i_min).abs().max()))

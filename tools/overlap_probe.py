@@ -25,7 +25,7 @@ with torch.no_grad():
     st = R._fused_style or fused.prepare_style(R)
     st["consts"][st["sky_off"]:st["sky_off"] + 64] = sky_avg.reshape(-1)
     net_out = torch.empty((n, 64), device=dev)
-    cnn = MfmaCNN(R)
+    cnn = MfmaCNN(R, int(os.environ.get("SDN_CNN_TERMS", "1")))
     x = torch.rand(1, cam_res[0], cam_res[1], 64, device=dev) * 2 - 1
     ori2 = torch.as_tensor(pose2[0], dtype=torch.float32)
     f2, c2, _ = camera.frame_intrinsics(pose2[3], (540, 960), 30)

@@ -9,8 +9,11 @@ streams (mlp_kernel: feature + weight streams, conv_kernel: LDS-DMA streams); en
 calibrated pattern -> left raw; WRITE_SIZE raw (checks against encode_kernel's known 512 B/sample feature write).
 """
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 KERNELS = {"mlp_kernel": ("mlp_kernel", 2.0), "encode_kernel": ("encode_kernel", 1.0), "conv_kernel<9>": ("conv_kernel<9", 2.0),
            "conv_kernel<1>": ("conv_kernel<1", 2.0), "sky_kernel": ("sky_kernel", 2.0), "rvip_kernel": ("rvip_kernel", 1.0)}
@@ -35,7 +38,9 @@ def main(fetch_db, write_db, mfma_db, commit):
     f_rows, _ = counters(fetch_db)
     w_rows, _ = counters(write_db)
     m_rows, m_dur = counters(mfma_db)
+    from scenedreamer_amd import build
     out = {"commit": commit,
+           "csrc_digest": build._digest(),    # renderer._profiled_traffic() refuses this profile once the kernel sources change
            "source": "rocprofv3 --kernel-trace --pmc <one counter set per pass> on tools/frame_once.py fused 3 (frames of poses 0, 2, 4 of "
                      "the headline config, field / CNN on the 4-px apron), tools/prof_round.sh; summarised by tools/pmc_traffic.py",
            "correction": "KiB -> bytes; FETCH_SIZE x2 for 16 B/lane streaming readers (mlp_kernel, conv_kernel, sky_kernel) per "

@@ -22,7 +22,7 @@ with torch.no_grad():
     buf = fused.encode(R, vid, d2, rd, ori, 24)
     st = R._fused_style or fused.prepare_style(R)
     net_out = torch.empty((n, 64), device=dev)
-    cnn = MfmaCNN(R)
+    cnn = MfmaCNN(R, int(os.environ.get("SDN_CNN_TERMS", "1")))
     x = torch.rand(1, cam_res[0], cam_res[1], 64, device=dev) * 2 - 1
     fns = {
         "mlp": lambda: fused._launch_mlp(R, buf, st, sky_c, sky_avg.reshape(-1), net_out, n, 24),
