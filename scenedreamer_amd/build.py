@@ -25,7 +25,9 @@ SOURCES = {
     "posenc.hip": [],
     "gridenc.hip": [],
     # no SLP vectorisation: hipcc pairs fp32 ops into v_pk_* and pays for it with v_mov shuffles and spills in the MLP kernel
-    "field.hip": ["-fno-slp-vectorize"] + (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
+    # (SDN_FIELD_CFLAGS: extra -D switches for timing ablations, tools/ab_libs.sh -- never set for a product build)
+    "field.hip": ["-fno-slp-vectorize"] + (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else [])
+                 + os.environ.get("SDN_FIELD_CFLAGS", "").split(),
     "cnn.hip": (["-DSDN_MLP_ABLATION"] if os.environ.get("SDN_MLP_ABLATION") else []),
     "scene.hip": [],
 }
@@ -41,6 +43,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256()
+    h.update(os.environ.get("SDN_FIELD_CFLAGS", "").encode())
     names = sorted(n for n in os.listdir(CSRC) if n.endswith((".hip", ".h"))) + ["../../include/sdnative.h", "../build.py"]
     for n in names:
         p = os.path.join(CSRC, n)

@@ -434,7 +434,10 @@ __device__ __forceinline__ float normalise_coord(float wc, float delim) {
     return n / 2.f;
 }
 
-__global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
+#ifndef SDN_ENC_OCC
+#define SDN_ENC_OCC 1
+#endif
+__global__ __launch_bounds__(256, SDN_ENC_OCC) void encode_kernel(const EncParams p) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= p.n_tiles) return;
@@ -532,7 +535,9 @@ __global__ __launch_bounds__(256) void encode_kernel(const EncParams p) {
             split8(res, hi8, lo8);
             typedef unsigned int u4v __attribute__((ext_vector_type(4)));
             __builtin_nontemporal_store(__builtin_bit_cast(u4v, hi8), reinterpret_cast<u4v *>(o));
+#ifndef SDN_ENC_HI_ONLY   // (timing ablation: upper bound of what fewer feature bytes can buy)
             __builtin_nontemporal_store(__builtin_bit_cast(u4v, lo8), reinterpret_cast<u4v *>(o + 4));
+#endif
         }
     }
     // per-ray flags: any over the ray's 4 lanes
@@ -796,49 +801,31 @@ __device__ __forceinline__ float vmax(float a, float b) {
     return r;
 }
 
-// Bias vector of row block IB in accumulator layout, read from LDS STRAIGHT INTO ACCUMULATOR REGISTERS ("=a": the unified
-// register file lets a DS load land in AGPRs) and WITHOUT a wait: it is the C operand of the row block's first MFMA
-// (k-step 0), so the layer bias costs no VALU instruction at all -- neither the v_add per value of an activation-stage
-// bias (one of ~5.5 VALU instructions per value in a kernel whose non-MFMA issue slots are the limit) nor the 16
-// v_accvgpr_write per row block of a seed that arrives in VGPRs.  The reads are issued one unit ahead of the MFMA that
-// consumes them, in front of that unit's fragment prefetches, so the unit-start wait `lgkmcnt(4)` covers them (see
-// ds_read16); tools/check_lds_hazards.py verifies it on the ISA.
+// bias vector of row block IB in accumulator layout (it seeds the accumulator: first MFMA's C operand)
 template <int IB>
-__device__ __forceinline__ void seed_fetch(const float *bias, int h, f32x16 &c) {
-    f32x4 v0, v1, v2, v3;
-    asm volatile(
-        "ds_read_b128 %0, %4 offset:%5\n\t"
-        "ds_read_b128 %1, %4 offset:%5+32\n\t"
-        "ds_read_b128 %2, %4 offset:%5+64\n\t"
-        "ds_read_b128 %3, %4 offset:%5+96"
-        : "=a"(v0), "=a"(v1), "=a"(v2), "=a"(v3)
-        : "v"(lds_addr(bias + 4 * h)), "n"(IB * 128));
-    const auto lo = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-    const auto hi = __builtin_shufflevector(v2, v3, 0, 1, 2, 3, 4, 5, 6, 7);
-    c = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+__device__ __forceinline__ f32x16 bias_block(const float *bias, int h) {
+    return lds_read_block(bias + 32 * IB + 4 * h);
 }
 
-// Activation of 4 accumulator values (half a B fragment), cut into stages of <= 4 mutually INDEPENDENT VALU
+// Activation of 4 accumulator values (half a B fragment), cut into 6 stages of <= 6 mutually INDEPENDENT VALU
 // instructions.  With one wave per SIMD instructions issue in order: a VALU instruction behind an MFMA that waits
 // for the matrix pipe waits too, and back-to-back dependent VALU instructions cost ~10 cycles each.  Putting one
-// stage after each of a unit's 6 MFMAs (and fencing with sched_barrier) gives every MFMA gap a few independent
+// stage after each of a unit's 6 MFMAs (and fencing with sched_barrier) gives every MFMA gap ~5 independent
 // instructions: the activation then costs no matrix time.  (Measured before this change: the same instructions,
 // emitted as per-value dependent chains after the unit's last MFMA, took 9.2 ms of a 19.2 ms kernel.)
 //   fragment T = 2*IB + Q of the next layer, HS = which 4 of its 8 elements:
 //   value e is accumulator register 8*Q + 4*HS + e of row block IB = feature 32*IB + 16*Q + 8*HS + e + 4*h
-// 14 VALU instructions per half fragment (round 3; 22 before): accumulator read (4), a' = 1.5 x + |x| (4), hi pair
-// conversions (2), and the lo halves as x - float(hi) rounded to f16 in ONE instruction per value (v_fma_mixlo/hi_f16
-// write the f16 result into the low / high half of the pair's dword: no separate remainder + pack conversion).  The
-// layer bias is not added here any more: it arrives as the C operand of the row block's first MFMA (seed_fetch).
-// For fc_4 the 4 density-head weights of the half fragment are fetched one unit ahead (ActIn), in front of that unit's
-// fragment prefetches, so the unit-start wait covers them.
+// The layer bias is added HERE (one v_add per value) instead of seeding the accumulators: a seed costs 16
+// v_accvgpr_write per row block plus an LDS read that has to be waited for right in front of the block's first MFMA.
+// The 4 bias values (and, for fc_4, the 4 density-head weights) of a half fragment are fetched one unit ahead
+// (ActIn), in front of that unit's fragment prefetches, so the unit-start wait covers them.
 struct ActRegs {
     float x[4], y[4];
-    fp16x2 hp[2];
-    unsigned int lp[2];
+    fp16x2 hp[2], lp[2];
 };
 
 struct ActIn {
+    f32x4 b;   // bias of the 4 features
     f32x4 w;   // density-head weights of the 4 features (SIG only)
 };
 
@@ -852,17 +839,18 @@ __device__ __forceinline__ float vmax_raw(float a, float b) {
 // write two packed f16 pairs into dwords 2*HS, 2*HS+1 of a fragment (whole-dword moves: 16-bit element inserts
 // into a half8 are lowered through scratch memory by hipcc)
 template <int HS>
-__device__ __forceinline__ void put_pairs(half8 &frag, unsigned int p0, unsigned int p1) {
+__device__ __forceinline__ void put_pairs(half8 &frag, fp16x2 p0, fp16x2 p1) {
     u32x4v t = __builtin_bit_cast(u32x4v, frag);
-    t[2 * HS] = p0;
-    t[2 * HS + 1] = p1;
+    t[2 * HS] = __builtin_bit_cast(unsigned int, p0);
+    t[2 * HS + 1] = __builtin_bit_cast(unsigned int, p1);
     frag = __builtin_bit_cast(half8, t);
 }
 
-// issue (no wait) the LDS read of a half fragment's density-head weights
+// issue (no wait) the LDS reads of a half fragment's activation inputs
 template <int T, int HS, bool SIG>
-__device__ __forceinline__ void act_fetch(const float *wsig, int h, ActIn &in) {
+__device__ __forceinline__ void act_fetch(const float *bias, const float *wsig, int h, ActIn &in) {
     constexpr int F = 32 * (T / 2) + 16 * (T % 2) + 8 * HS;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(in.b) : "v"(lds_addr(bias + 4 * h)), "n"(F * 4));
     if constexpr (SIG) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(in.w) : "v"(lds_addr(wsig + 4 * h)), "n"(F * 4));
 }
 
@@ -875,41 +863,44 @@ __device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const ActIn &i
 #pragma unroll
         for (int e = 0; e < 4; e++) g.y[e] = acc[IB][8 * Q + 4 * HS + e];                 // 4 x v_accvgpr_read
     } else if constexpr (STAGE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) g.y[e] += in.b[e];
+    } else if constexpr (STAGE == 2) {
         // a' = 1.5 x + |x| = LeakyReLU_0.2(x) / 0.4 : ONE v_fma (|x| is a free source modifier); the 0.4 lives in
         // the next layer's packed weights and in the density-head weights
 #pragma unroll
         for (int e = 0; e < 4; e++) g.x[e] = __builtin_fmaf(g.y[e], 1.5f, __builtin_fabsf(g.y[e]));
-    } else if constexpr (STAGE == 2) {
+    } else if constexpr (STAGE == 3) {
         g.hp[0] = cvt_rtn(g.x[0], g.x[1]);
         g.hp[1] = cvt_rtn(g.x[2], g.x[3]);
         if constexpr (SIG) part += in.w[0] * g.x[0] + in.w[1] * g.x[1] + in.w[2] * g.x[2] + in.w[3] * g.x[3];
-    } else if constexpr (STAGE == 3) {
-        if constexpr (!LO) return;
-        // lo = f16(x - float(hi)): x - hi is exact in f32 (hi is x rounded to 11 bits), so the single rounding of the fused
-        // instruction equals the former v_fma_mix_f32 + v_cvt_pk_f16_f32 pair bit for bit.  Low halves of both pairs first,
-        // high halves in the next stage: the two writes of one dword are dependent.
-        const unsigned int p0 = __builtin_bit_cast(unsigned int, g.hp[0]), p1 = __builtin_bit_cast(unsigned int, g.hp[1]);
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.lp[0]) : "v"(p0), "v"(g.x[0]));
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.lp[1]) : "v"(p1), "v"(g.x[2]));
     } else if constexpr (STAGE == 4) {
         if constexpr (!LO) return;
+        // remainder x - float(hi) in one v_fma_mix_f32 per value (reads the f16 half directly)
         const unsigned int p0 = __builtin_bit_cast(unsigned int, g.hp[0]), p1 = __builtin_bit_cast(unsigned int, g.hp[1]);
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(g.lp[0]) : "v"(p0), "v"(g.x[1]));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(g.lp[1]) : "v"(p1), "v"(g.x[3]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[0]) : "v"(p0), "v"(g.x[0]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[1]) : "v"(p0), "v"(g.x[1]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[2]) : "v"(p1), "v"(g.x[2]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[3]) : "v"(p1), "v"(g.x[3]));
     } else {
-        put_pairs<HS>(bh[T], __builtin_bit_cast(unsigned int, g.hp[0]), __builtin_bit_cast(unsigned int, g.hp[1]));
-        if constexpr (LO) put_pairs<HS>(bl[T], g.lp[0], g.lp[1]);
+        put_pairs<HS>(bh[T], g.hp[0], g.hp[1]);
+        if constexpr (LO) {
+            g.lp[0] = cvt_rtn(g.y[0], g.y[1]);
+            g.lp[1] = cvt_rtn(g.y[2], g.y[3]);
+            put_pairs<HS>(bl[T], g.lp[0], g.lp[1]);
+        }
     }
 }
 
 // whole half-fragment at once (used where nothing can hide it: the tail of the first layer)
 template <int T, int HS, bool SIG>
-__device__ __forceinline__ void act_half(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16],
+__device__ __forceinline__ void act_half(const f32x16 (&acc)[8], const float *bias, const float *wsig, int h, half8 (&bh)[16],
                                          half8 (&bl)[16], float &part) {
     ActRegs g;
     ActIn in;
-    act_fetch<T, HS, SIG>(wsig, h, in);
-    if constexpr (SIG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in.w)::"memory");
+    act_fetch<T, HS, SIG>(bias, wsig, h, in);
+    if constexpr (SIG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in.b), "+v"(in.w)::"memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in.b)::"memory");
     act_stage<T, HS, SIG, 0>(acc, in, bh, bl, part, g);
     act_stage<T, HS, SIG, 1>(acc, in, bh, bl, part, g);
     act_stage<T, HS, SIG, 2>(acc, in, bh, bl, part, g);
@@ -919,14 +910,14 @@ __device__ __forceinline__ void act_half(const f32x16 (&acc)[8], const float *ws
 }
 
 template <int T, bool SIG>
-__device__ __forceinline__ void act_step(const f32x16 (&acc)[8], const float *wsig, int h, half8 (&bh)[16],
+__device__ __forceinline__ void act_step(const f32x16 (&acc)[8], const float *bias, const float *wsig, int h, half8 (&bh)[16],
                                          half8 (&bl)[16], float &part) {
-    act_half<T, 0, SIG>(acc, wsig, h, bh, bl, part);
-    act_half<T, 1, SIG>(acc, wsig, h, bh, bl, part);
+    act_half<T, 0, SIG>(acc, bias, wsig, h, bh, bl, part);
+    act_half<T, 1, SIG>(acc, bias, wsig, h, bh, bl, part);
 }
 
 // One 8-row-block layer (NS k-steps) from the LDS ring.
-//   pend:  activation of the PREVIOUS layer's lower half (row blocks 4-7 -> B fragments 8..15), one
+//   pend:  activation of the PREVIOUS layer's lower half (row blocks 4-7 -> B fragments 8..15, bias_pend), one
 //          half fragment per unit from unit 0 (HAS_PEND), hidden behind this layer's first MFMAs;
 //   own:   activation of this layer's upper half into B fragments 0 .. NS/2-1 during the last NS/2 k-steps of
 //          the lower half.
@@ -938,7 +929,6 @@ constexpr int RING_DEPTH = 3;   // register ring of fragment units: 2 units (384
 struct LayerState {
     half8 ring[RING_DEPTH][4];
     ActIn in[2];                // activation inputs of unit U in in[U & 1], fetched during unit U-1
-    f32x16 seed[4];             // bias seeds (C operands) of the row blocks a k-step-0 unit starts, fetched during the unit before
     int pos_cur, pos_nxt;
 };
 
@@ -969,24 +959,10 @@ struct ActPlan {
     static constexpr bool ACT = PEND || OWN;
 };
 
-// LDS reads unit U needs besides its fragments, issued (no wait) during unit U-1: the density-head weights of the half
-// fragment it activates, and -- when it is a k-step-0 unit -- the bias seeds of the row blocks it starts.
-// MX = the MX unit order (layer8x: a k-step-0 unit starts all 4 row blocks of its half), else 2 row blocks per unit.
-template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U, bool MX = false>
-__device__ __forceinline__ void layer8_fetch(const float *bias, const float *wsig, int h, LayerState &st) {
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
+__device__ __forceinline__ void layer8_fetch(const float *bias, const float *bias_pend, const float *wsig, int h, LayerState &st) {
     using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U>;
-    if constexpr (P::ACT) act_fetch<P::T, P::HS, P::SIG>(wsig, h, st.in[U & 1]);
-    if constexpr (P::IN_RANGE && MX) {
-        if constexpr (U % 32 == 0) {
-            constexpr int IB0 = 4 * (U / 32);
-            seed_fetch<IB0>(bias, h, st.seed[0]); seed_fetch<IB0 + 1>(bias, h, st.seed[1]);
-            seed_fetch<IB0 + 2>(bias, h, st.seed[2]); seed_fetch<IB0 + 3>(bias, h, st.seed[3]);
-        }
-    } else if constexpr (P::IN_RANGE && P::S == 0) {
-        constexpr int IB = 4 * P::HALF + 2 * (P::REM & 1);
-        seed_fetch<IB>(bias, h, st.seed[0]);
-        seed_fetch<IB + 1>(bias, h, st.seed[1]);
-    }
+    if constexpr (P::ACT) act_fetch<P::T, P::HS, P::SIG>(P::PEND ? bias_pend : bias, wsig, h, st.in[U & 1]);
 }
 
 // TERMS = 3: Whi.Xhi + Wlo.Xhi + Whi.Xlo (6 MFMAs per unit);  TERMS = 2: the Whi.Xlo products are dropped (4 MFMAs per
@@ -995,7 +971,8 @@ __device__ __forceinline__ void layer8_fetch(const float *bias, const float *wsi
 // half) need their lo part, i.e. whether their CONSUMER is a 3-term layer.
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS, bool LO_PEND, bool LO_OWN, int U>
 __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
-                                            f32x16 (&acc)[8], const float *bias, const float *wsig, int h, float &part) {
+                                            f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
+                                            int h, float &part) {
     constexpr int UNITS = NS * 4, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
     using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U>;
     if constexpr (U % UPS == 0 && U != 0) {
@@ -1017,10 +994,7 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     // landed once only unit U-1's 4 fragment reads are outstanding
     constexpr bool PF_PREV = U == 0 || ((U - 1 + RD - 1) < UNITS && !(DBG & 8));
     lds_wait<PF_PREV ? 4 : 0>();
-    // the seeds of this unit (if it is a k-step-0 unit) are taken over BEFORE the next unit's are fetched into the same slots
-    f32x16 c0, c1;
-    if constexpr (S == 0) { c0 = st.seed[0]; c1 = st.seed[1]; }
-    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1>(bias, wsig, h, st);
+    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
     if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
     if constexpr (ACT) act_stage<T, HS, SIG, K, LO>(acc, in, bh, bl, part, g); \
@@ -1028,14 +1002,14 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DBG & 16) {
         asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(bh[S]), "v"(bl[S]));
-        if constexpr (S == 0) { acc[IB] = c0; acc[IB + 1] = c1; }
+        if constexpr (S == 0) { acc[IB] = zero16(); acc[IB + 1] = zero16(); }
         SDN_STAGE(0) SDN_STAGE(1) SDN_STAGE(2) SDN_STAGE(3) SDN_STAGE(4) SDN_STAGE(5)
     } else if constexpr (TERMS == 2) {
-        // 4 MFMAs: the six activation stages share four gaps (stages 3, 4 are empty and stage 5 a single move when !LO)
-        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], c0);
+        // 4 MFMAs: the six activation stages share four gaps (stage 4 is empty and stage 5 a single move when !LO)
+        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], zero16());
         else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
         SDN_STAGE(0) SDN_STAGE(1)
-        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], c1);
+        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], zero16());
         else acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
         SDN_STAGE(2)
         acc[IB] = mfma16(a[1], bh[S], acc[IB]);
@@ -1043,10 +1017,10 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
         acc[IB + 1] = mfma16(a[3], bh[S], acc[IB + 1]);
         SDN_STAGE(4) SDN_STAGE(5)
     } else {
-        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], c0);
+        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], zero16());
         else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
         SDN_STAGE(0)
-        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], c1);
+        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], zero16());
         else acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
         SDN_STAGE(1)
         acc[IB] = mfma16(a[1], bh[S], acc[IB]);
@@ -1064,21 +1038,21 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS, bool LO_PEND, bool LO_OWN, int... Us>
 __device__ __forceinline__ void layer8_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
                                              half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8], const float *bias,
-                                             const float *wsig, int h, float &part) {
-    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN, Us>(lds, r, st, bh, bl, acc, bias, wsig, h, part), ...);
+                                             const float *bias_pend, const float *wsig, int h, float &part) {
+    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN, Us>(lds, r, st, bh, bl, acc, bias, bias_pend, wsig, h, part), ...);
 }
 
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS = 3, bool LO_PEND = true, bool LO_OWN = true>
 __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
-                                       const float *bias, const float *wsig, int h, float &part) {
+                                       const float *bias, const float *bias_pend, const float *wsig, int h, float &part) {
     LayerState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
-    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, 0>(bias, wsig, h, st);
+    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, 0>(bias, bias_pend, wsig, h, st);
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
     layer8_units<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh,
-                                                                             bl, acc, bias, wsig, h, part);
+                                                                             bl, acc, bias, bias_pend, wsig, h, part);
 }
 
 // =====================================================================================================
@@ -1185,7 +1159,8 @@ __device__ __forceinline__ void act_stage_x(const f32x16 (&acc)[8], const ActIn 
 // The activation schedule (which half fragment is activated behind which unit) is layer8's.
 template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN, int U>
 __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16], MxState &mx,
-                                             f32x16 (&acc)[8], const float *bias, const float *wsig, int h, float &part) {
+                                             f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
+                                             int h, float &part) {
     constexpr int NS = 16, UNITS = 64, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
     constexpr bool MXL = KIND != 0;
     using P = ActPlan<DBG, NS, true, SIG_PEND, SIG_OWN, U>;
@@ -1208,14 +1183,7 @@ __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st,
     const ActIn &in = st.in[U & 1];
     constexpr bool PF_PREV = U == 0 || (U - 1 + RD - 1) < UNITS;
     lds_wait<PF_PREV ? 4 : 0>();
-    // bias seeds of the row blocks this unit starts, taken over before the next unit's fetch reuses the slots: two row blocks
-    // in the plain unit order (k-step 0 of a row-block pair), all four of a half in the MX order (its first unit is k-step 0
-    // of the half's four row blocks)
-    constexpr bool SEED2 = !MXL && P::S == 0, SEED4 = MXL && U % 32 == 0;
-    f32x16 c0, c1, c2, c3;
-    if constexpr (SEED2 || SEED4) { c0 = st.seed[0]; c1 = st.seed[1]; }
-    if constexpr (SEED4) { c2 = st.seed[2]; c3 = st.seed[3]; }
-    layer8_fetch<DBG, NS, true, SIG_PEND, SIG_OWN, U + 1, MXL>(bias, wsig, h, st);
+    layer8_fetch<DBG, NS, true, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
     if constexpr (U % UPS < PIECES / 4 && K < 4) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
     if constexpr (CONV >= 0 && K == 0) mx_convert<CONV < 0 ? 0 : CONV>(bh, bl, mx); \
@@ -1224,10 +1192,10 @@ __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st,
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!MXL) {
         constexpr int S = P::S, IB = 4 * P::HALF + 2 * (P::REM & 1);
-        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], c0);
+        if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], zero16());
         else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
         SDN_STAGE(0)
-        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], c1);
+        if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], zero16());
         else acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
         SDN_STAGE(1)
         acc[IB] = mfma16(a[1], bh[S], acc[IB]);
@@ -1242,16 +1210,16 @@ __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st,
         constexpr int HALF = U / 32, KB = (U % 32) / 8, SUB = U % 8, IB0 = 4 * HALF;
         if constexpr (SUB < 4) {
             constexpr int S = 4 * KB + SUB;
-            if constexpr (S == 0) acc[IB0] = mfma16(a[0], bh[S], c0);
+            if constexpr (S == 0) acc[IB0] = mfma16(a[0], bh[S], zero16());
             else acc[IB0] = mfma16(a[0], bh[S], acc[IB0]);
             SDN_STAGE(0) SDN_STAGE(1)
-            if constexpr (S == 0) acc[IB0 + 1] = mfma16(a[1], bh[S], c1);
+            if constexpr (S == 0) acc[IB0 + 1] = mfma16(a[1], bh[S], zero16());
             else acc[IB0 + 1] = mfma16(a[1], bh[S], acc[IB0 + 1]);
             SDN_STAGE(2)
-            if constexpr (S == 0) acc[IB0 + 2] = mfma16(a[2], bh[S], c2);
+            if constexpr (S == 0) acc[IB0 + 2] = mfma16(a[2], bh[S], zero16());
             else acc[IB0 + 2] = mfma16(a[2], bh[S], acc[IB0 + 2]);
             SDN_STAGE(3)
-            if constexpr (S == 0) acc[IB0 + 3] = mfma16(a[3], bh[S], c3);
+            if constexpr (S == 0) acc[IB0 + 3] = mfma16(a[3], bh[S], zero16());
             else acc[IB0 + 3] = mfma16(a[3], bh[S], acc[IB0 + 3]);
             SDN_STAGE(4) SDN_STAGE(5)
         } else {
@@ -1272,34 +1240,42 @@ __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st,
 template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN, int... Us>
 __device__ __forceinline__ void layer8x_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st, half8 (&bh)[16],
                                               half8 (&bl)[16], MxState &mx, f32x16 (&acc)[8], const float *bias,
-                                              const float *wsig, int h, float &part) {
-    (layer8x_unit<DBG, KIND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, mx, acc, bias, wsig, h, part), ...);
+                                              const float *bias_pend, const float *wsig, int h, float &part) {
+    (layer8x_unit<DBG, KIND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, mx, acc, bias, bias_pend, wsig, h, part), ...);
 }
 
 template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN>
 __device__ __forceinline__ void layer8x(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], MxState &mx, f32x16 (&acc)[8],
-                                        const float *bias, const float *wsig, int h, float &part) {
+                                        const float *bias, const float *bias_pend, const float *wsig, int h, float &part) {
     LayerState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
-    layer8_fetch<DBG, 16, true, SIG_PEND, SIG_OWN, 0, KIND != 0>(bias, wsig, h, st);
+    layer8_fetch<DBG, 16, true, SIG_PEND, SIG_OWN, 0>(bias, bias_pend, wsig, h, st);
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
-    layer8x_units<DBG, KIND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, 64>{}, lds, r, st, bh, bl, mx, acc, bias, wsig, h,
-                                                part);
+    layer8x_units<DBG, KIND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, 64>{}, lds, r, st, bh, bl, mx, acc, bias, bias_pend,
+                                                wsig, h, part);
 }
 
 // Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of the last hidden layer is
 // activated behind its first 8 k-steps (one whole fragment = two half fragments per unit).
 struct OutState {
     half8 ring[RING_DEPTH][4];
+    ActIn in[2][2];
     int pos_cur, pos_nxt;
 };
 
+template <int DBG, int U>
+__device__ __forceinline__ void out_fetch(const float *bias_pend, int h, OutState &st) {
+    if constexpr (U < 8 && !(DBG & 4)) {
+        act_fetch<8 + U, 0, false>(bias_pend, bias_pend, h, st.in[U & 1][0]);
+        act_fetch<8 + U, 1, false>(bias_pend, bias_pend, h, st.in[U & 1][1]);
+    }
+}
 
 template <int DBG, int U>
 __device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8 (&bh)[16], half8 (&bl)[16],
-                                         const f32x16 (&acc)[8], f32x16 (&col)[2], float &part) {
+                                         const f32x16 (&acc)[8], f32x16 (&col)[2], const float *bias_pend, int h, float &part) {
     constexpr int UNITS = 16, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
     if constexpr (U % UPS == 0 && U != 0) {
         st.pos_cur = ring_acquire<DBG>(lds, r);
@@ -1314,9 +1290,10 @@ __device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8
     ActRegs g0, g1;
     half8(&a)[4] = st.ring[U % RD];
     half8(&nx)[4] = st.ring[UN % RD];
-    const ActIn in0{}, in1{};       // (no density head behind fc_6: nothing to fetch)
+    const ActIn &in0 = st.in[U & 1][0], &in1 = st.in[U & 1][1];
     constexpr bool PF_PREV = U == 0 || ((U - 1 + RD - 1) < UNITS && !(DBG & 8));
     lds_wait<PF_PREV ? 4 : 0>();
+    out_fetch<DBG, U + 1>(bias_pend, h, st);
 #define SDN_STAGE(K) \
     if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
     if constexpr (ACT) { act_stage<T, 0, false, K>(acc, in0, bh, bl, part, g0); act_stage<T, 1, false, K>(acc, in1, bh, bl, part, g1); } \
@@ -1340,21 +1317,20 @@ __device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8
 template <int DBG, int... Us>
 __device__ __forceinline__ void out_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, OutState &st,
                                           half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8], f32x16 (&col)[2],
-                                          float &part) {
-    (out_unit<DBG, Us>(lds, r, st, bh, bl, acc, col, part), ...);
+                                          const float *bias_pend, int h, float &part) {
+    (out_unit<DBG, Us>(lds, r, st, bh, bl, acc, col, bias_pend, h, part), ...);
 }
 
-// col[0], col[1] arrive seeded with fc_out_c's bias (seed_fetch issued by the caller, NOT yet waited for: the first unit's
-// wait covers them, like a layer8 seed)
 template <int DBG>
 __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8],
-                                          f32x16 (&col)[2], float &part) {
+                                          f32x16 (&col)[2], const float *bias_pend, int h, float &part) {
     OutState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    out_fetch<DBG, 0>(bias_pend, h, st);
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
-    out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, part);
+    out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, bias_pend, h, part);
 }
 
 // CT = number of split terms of the colour layers fc_5 / fc_6 (3, or 2 = without the Whi.Xlo products)
@@ -1516,24 +1492,25 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             // ---- fc_1: 8 k-steps; fragments 0..6 of its upper half are activated behind its own lower half, fragment 7
             //      right after it, its lower half behind fc_2's head ---------------------------------------------------
             const float *bias1 = cst + C_LABEL_BIAS + lab * HID;
-            layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, bias1, wsig, h, part);
-            act_step<7, false>(acc, wsig, h, bh, bl, part);   // fragments 0..6 were activated inside the layer
+            layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, bias1, bias1, wsig, h, part);
+            act_step<7, false>(acc, bias1, wsig, h, bh, bl, part);   // fragments 0..6 were activated inside the layer
             // ---- fc_2 .. fc_6.  fc_4 (l == 2) feeds the density head (layers.py:114): its upper half is activated
             //      inside l == 2, its lower half as the pending work of l == 3 ----------------------------------------
 #pragma unroll 1
             for (int l = 0; l < 5; l++) {   // (straight-line code instead of this loop: 1.5 KB of scratch spills -- tried)
                 const float *bias = cst + C_BETA + l * HID;
+                const float *bias_pend = l == 0 ? bias1 : bias - HID;   // the previous layer's (its lower half is pending)
                 if constexpr (CT == 6) {   // colour layers: f16 Whi.Xhi + fp6 corrections (layer8x)
-                    if (l == 2) layer8x<DBG, 0, false, true>(lds, r, bh, bl, mx, acc, bias, wsig, h, part);
-                    else if (l == 3) layer8x<DBG, 1, true, false>(lds, r, bh, bl, mx, acc, bias, wsig, h, part);
-                    else if (l == 4) layer8x<DBG, 2, false, false>(lds, r, bh, bl, mx, acc, bias, wsig, h, part);
-                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
+                    if (l == 2) layer8x<DBG, 0, false, true>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
+                    else if (l == 3) layer8x<DBG, 1, true, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
+                    else if (l == 4) layer8x<DBG, 2, false, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
+                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
                 } else {
                     // fc_4's upper half feeds fc_5, fc_5's activations feed fc_5 / fc_6: no lo parts when those are 2-term
-                    if (l == 2) layer8<DBG, 16, true, false, true, 3, true, CT == 3>(lds, r, bh, bl, acc, bias, wsig, h, part);
-                    else if (l == 3) layer8<DBG, 16, true, true, false, CT, CT == 3, CT == 3>(lds, r, bh, bl, acc, bias, wsig, h, part);
-                    else if (CT != 3 && l == 4) layer8<DBG, 16, true, false, false, CT, CT == 3, true>(lds, r, bh, bl, acc, bias, wsig, h, part);
-                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, wsig, h, part);
+                    if (l == 2) layer8<DBG, 16, true, false, true, 3, true, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                    else if (l == 3) layer8<DBG, 16, true, true, false, CT, CT == 3, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                    else if (CT != 3 && l == 4) layer8<DBG, 16, true, false, false, CT, CT == 3, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
                 }
             }
             // ---- fc_out_c ------------------------------------------------------------------------------------------
@@ -1568,9 +1545,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 }
             }
             f32x16 col[2];
-            seed_fetch<0>(cst + C_BC, h, col[0]);     // fc_out_c's bias: the C operands of its first MFMAs (landed by unit 0's wait)
-            seed_fetch<1>(cst + C_BC, h, col[1]);
-            layer_out<DBG>(lds, r, bh, bl, acc, col, part);
+            col[0] = bias_block<0>(cst + C_BC, h);
+            col[1] = bias_block<1>(cst + C_BC, h);
+            layer_out<DBG>(lds, r, bh, bl, acc, col, cst + C_BETA + 4 * HID, h, part);
             const float sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
             // ---- volume rendering (mc_utils.py:154-161) over the 4 samples of each ray in this pass ---------------
             const float fe = fmaxf(sigma, 0.f) * dist;
@@ -1783,12 +1760,12 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
         const float *nul = cst;
         // fc1 (+ style term): 4 k-steps; fragments 0..2 of its upper half are activated behind its own lower half, the
         // remaining five (3..7) right after, the lower half behind fc2's head
-        layer8<DBG, 4, false, false, false>(lds, r, bh, bl, acc, cst + SC_BIAS1, nul, h, part);
-        act_step<3, false>(acc, nul, h, bh, bl, part);   // fragments 0..2 were activated inside the layer
-        act_step<4, false>(acc, nul, h, bh, bl, part);
-        act_step<5, false>(acc, nul, h, bh, bl, part);
-        act_step<6, false>(acc, nul, h, bh, bl, part);
-        act_step<7, false>(acc, nul, h, bh, bl, part);
+        layer8<DBG, 4, false, false, false>(lds, r, bh, bl, acc, cst + SC_BIAS1, cst + SC_BIAS1, nul, h, part);
+        act_step<3, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);   // fragments 0..2 were activated inside the layer
+        act_step<4, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<5, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<6, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
+        act_step<7, false>(acc, cst + SC_BIAS1, nul, h, bh, bl, part);
         if constexpr (SMX) {
             // fc1's upper half (fragments 0..7 = K blocks 0, 1) was activated by the plain stages: block maxima from the
             // fragments, K block 0 converted here, K block 1 by fc2's first unit (the protocol of layer8x)
@@ -1799,19 +1776,20 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
             mx_convert<0>(bh, bl, mx);
 #pragma unroll 1
             for (int l = 0; l < 4; l++) {
-                const float *bias = cst + SC_BIASH + l * HID;
-                if (l < 3) layer8x<DBG, 1, false, false>(lds, r, bh, bl, mx, acc, bias, nul, h, part);
-                else layer8x<DBG, 2, false, false>(lds, r, bh, bl, mx, acc, bias, nul, h, part);
+                const float *bias = cst + SC_BIASH + l * HID, *bias_pend = l == 0 ? cst + SC_BIAS1 : cst + SC_BIASH + (l - 1) * HID;
+                if (l < 3) layer8x<DBG, 1, false, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, nul, h, part);
+                else layer8x<DBG, 2, false, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, nul, h, part);
             }
         } else {
 #pragma unroll 1
             for (int l = 0; l < 4; l++)
-                layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, cst + SC_BIASH + l * HID, nul, h, part);
+                layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, cst + SC_BIASH + l * HID,
+                                                    l == 0 ? cst + SC_BIAS1 : cst + SC_BIASH + (l - 1) * HID, nul, h, part);
         }
         f32x16 col[2];
-        seed_fetch<0>(cst + SC_BC, h, col[0]);
-        seed_fetch<1>(cst + SC_BC, h, col[1]);
-        layer_out<DBG>(lds, r, bh, bl, acc, col, part);
+        col[0] = bias_block<0>(cst + SC_BC, h);
+        col[1] = bias_block<1>(cst + SC_BC, h);
+        layer_out<DBG>(lds, r, bh, bl, acc, col, cst + SC_BIASH + 3 * HID, h, part);
         // ---- store sky_c[ray][feature] and accumulate the per-feature sum over rays -----------------------------
         if (ray_ok) {
 #pragma unroll

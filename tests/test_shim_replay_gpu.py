@@ -107,3 +107,74 @@ def test_unmodified_generator_on_hip_shims(scene256, weights_full):
         np.testing.assert_array_equal(vid.cpu().numpy(), g["voxel_id"])
         np.testing.assert_allclose(out[0].cpu().numpy(), g["net_out"], rtol=0, atol=1e-3)
         np.testing.assert_allclose(img.cpu().numpy(), g["image"], rtol=0, atol=1e-3)
+
+
+@pytest.mark.needs_reference
+def test_unmodified_inference_givenstyle_loop_on_hip_shims(scene256, weights_full, tmp_path):
+    """The reference's OWN frame loop -- Generator.inference_givenstyle (scenedreamer.py:479-632: camera controller, per-frame
+    voxlib ray casting, sky pre-pass, 2 x 2 tiles through _forward_perpix / _forward_global, crop + stitch, write_img, video
+    writer), UNCHANGED, with `voxlib` / `_gridencoder` served by libsdnative -- against this package's renderer on the same
+    scene, weights, style and trajectory.  cv2 / imageio do not exist in this image: cv2.imwrite is served by Pillow and
+    imageio.get_writer by a recorder (host-side file writing, not part of the path).  uint8 frames must agree to one level
+    (both truncate: a 1e-4 float difference moves a pixel across an integer boundary now and then), the scene maps exactly."""
+    import os
+
+    from PIL import Image
+    from oracle import ref_harness as RH
+    from scenedreamer_amd import camera, synth
+    from scenedreamer_amd.output import to_uint8_hwc, write_scene_maps
+    from scenedreamer_amd.renderer import Renderer
+    RH.install("hip")
+    import cv2
+    import imageio
+
+    def imwrite(path, img, params=None):
+        img = np.asarray(img)
+        Image.fromarray(img[..., ::-1] if img.shape[-1] == 3 else img[..., 0]).save(path)      # cv2 takes BGR
+        return True
+
+    class _Rec:
+        frames = []
+
+        def append_data(self, rgb):
+            _Rec.frames.append(np.asarray(rgb).copy())
+
+        def close(self):
+            pass
+
+    cv2.__dict__["imwrite"] = imwrite
+    cv2.__dict__["IMWRITE_PNG_COMPRESSION"] = 16
+    imageio.__dict__["get_writer"] = lambda path, fps=10: _Rec()
+    G, _ = RH.build_generator(weights_full, scene256)
+    G = G.cuda()
+    G.voxel.voxel_t = scene256.voxel_t.cuda()
+    G.voxel.current_height_map = scene256.current_height_map.cuda()
+    G.voxel.current_semantic_map = scene256.current_semantic_map.cuda()
+    hw, ns, steps = [72, 104], 12, 3
+    style = torch.from_numpy(np.asarray(synth.make_style(8888))).cuda()
+    out = str(tmp_path / "ref")
+    with torch.no_grad():
+        G.inference_givenstyle(style, out, camera_mode=0, num_samples=ns, tile_size=64, resolution_hw=hw, cam_ang=72,
+                               cam_maxstep=steps)
+    rdir = os.path.join(out, "rgb_render")
+    assert len(_Rec.frames) == steps and sorted(os.listdir(rdir)) == ["00000.png", "00001.png", "00002.png", "height_map.png",
+                                                                      "semantic_map.png", "style.npy"]
+    # ---- the same trajectory through this package
+    R = Renderer(weights_full, scene256, "cuda")
+    R.set_style(synth.make_style(8888))
+    poses = camera.eval_camera_poses(scene256, maxstep=steps, pattern=0, cam_ang=72)
+    worst, off = 0, 0.0
+    for f, img in enumerate(R.render_frames(poses, tuple(hw), ns, mode="fused")):
+        mine = to_uint8_hwc(img).cpu().numpy().astype(np.int32)
+        ref = np.asarray(Image.open(os.path.join(rdir, f"{f:05d}.png"))).astype(np.int32)
+        assert ref.shape == mine.shape == (hw[0], hw[1], 3) and ref.std() > 5
+        np.testing.assert_array_equal(ref, _Rec.frames[f].astype(np.int32))       # the video got the PNG's pixels
+        d = np.abs(ref - mine)
+        worst, off = max(worst, int(d.max())), max(off, float((d > 0).mean()))
+    print(f"inference_givenstyle (unmodified, HIP shims) vs scenedreamer_amd frames: max |diff| {worst} level, "
+          f"{100 * off:.2f} % of the values differ")
+    assert worst <= 1 and off < 0.2
+    sem, height = write_scene_maps(str(tmp_path / "mine"), scene256)
+    np.testing.assert_array_equal(np.asarray(Image.open(os.path.join(rdir, "semantic_map.png"))), sem)
+    np.testing.assert_array_equal(np.asarray(Image.open(os.path.join(rdir, "height_map.png"))), height)
+    np.testing.assert_array_equal(np.load(os.path.join(rdir, "style.npy")), np.asarray(synth.make_style(8888)))
