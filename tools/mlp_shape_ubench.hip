@@ -1,0 +1,330 @@
+// Micro-benchmark: the steady state of ONE 256 -> 256 hidden layer of the field MLP (3-term f16 split, weights through the
+// 4 x 32 KiB LDS-DMA ring, fragments by hand-waited ds_read_b128, activation stages in the MFMA gaps) in two shapes that do the
+// SAME work per CU and layer (128 samples):
+//   shape A (what mlp_kernel is): 4 waves / CU, one per SIMD, 32 samples per wave, v_mfma_f32_32x32x16_f16, 512 registers
+//   shape B (the alternative)   : 8 waves / CU, two per SIMD, 16 samples per wave, v_mfma_f32_16x16x32_f16, <= 256 registers
+// Numerically meaningless (operands are whatever is in the buffers); what is measured is time per layer.  Ideal matrix-pipe
+// time per layer and SIMD: 384 x 32 = 2 x 384 x 16 = 12 288 cycles in both shapes.
+//   hipcc -O3 --offload-arch=gfx950 -fno-slp-vectorize -o tools/mlp_shape_ubench tools/mlp_shape_ubench.hip && tools/mlp_shape_ubench
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+#include <utility>
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) const char glb_char;
+
+constexpr int SLOT_BYTES = 32768, NSLOT = 4, UPS = 8, LAYER_SLOTS = 8;   // 64 units of 4 KiB per layer
+constexpr int STREAM_SLOTS = 40;                                       // 1.25 MiB, L2 resident (like the packed weights)
+
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(const lds_char *)p; }
+
+template <int OFF>
+__device__ __forceinline__ void ds_read16(half8 &dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ fp16x2 cvt_rtn(float a, float b) {
+    return __builtin_bit_cast(fp16x2, __builtin_convertvector(float2v{a, b}, half2v));
+}
+
+struct Act {
+    float x[4], y[4];
+    fp16x2 hp[2], lp[2];
+    f32x4 b;
+};
+
+// the six activation stages of mlp_kernel (act_stage), on 4 values v[0..3] read from an accumulator; result -> two dwords of hi, lo
+template <int STAGE>
+__device__ __forceinline__ void act_stage(const float (&v)[4], Act &g, unsigned (&hi)[2], unsigned (&lo)[2]) {
+    if constexpr (STAGE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) g.y[e] = v[e];
+    } else if constexpr (STAGE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) g.y[e] += g.b[e];
+    } else if constexpr (STAGE == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) g.x[e] = __builtin_fmaf(g.y[e], 1.5f, __builtin_fabsf(g.y[e]));
+    } else if constexpr (STAGE == 3) {
+        g.hp[0] = cvt_rtn(g.x[0], g.x[1]);
+        g.hp[1] = cvt_rtn(g.x[2], g.x[3]);
+    } else if constexpr (STAGE == 4) {
+        const unsigned p0 = __builtin_bit_cast(unsigned, g.hp[0]), p1 = __builtin_bit_cast(unsigned, g.hp[1]);
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[0]) : "v"(p0), "v"(g.x[0]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[1]) : "v"(p0), "v"(g.x[1]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(g.y[2]) : "v"(p1), "v"(g.x[2]));
+        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(g.y[3]) : "v"(p1), "v"(g.x[3]));
+    } else {
+        g.lp[0] = cvt_rtn(g.y[0], g.y[1]);
+        g.lp[1] = cvt_rtn(g.y[2], g.y[3]);
+        hi[0] = __builtin_bit_cast(unsigned, g.hp[0]); hi[1] = __builtin_bit_cast(unsigned, g.hp[1]);
+        lo[0] = __builtin_bit_cast(unsigned, g.lp[0]); lo[1] = __builtin_bit_cast(unsigned, g.lp[1]);
+    }
+}
+
+template <int HS>
+__device__ __forceinline__ void put(half8 &f, const unsigned (&p)[2]) {
+    u32x4 t = __builtin_bit_cast(u32x4, f);
+    t[2 * HS] = p[0];
+    t[2 * HS + 1] = p[1];
+    f = __builtin_bit_cast(half8, t);
+}
+
+struct Ring {
+    const char *w;
+    int g, next, wave, pieces;    // pieces: 1-KiB DMA pieces per wave and slot (8 with 4 waves, 4 with 8 waves)
+    unsigned lds_lane;
+    char *lds;
+};
+
+template <int K>
+__device__ __forceinline__ void ring_dma(const char *src, char *dst) {
+    __builtin_amdgcn_global_load_lds((glb_char *)(src + (K / 4) * 4096), (lds_char *)(dst + (K / 4) * 4096), 16, (K % 4) * 1024, 0);
+}
+
+template <int PIECES>
+__device__ __forceinline__ void ring_issue(const Ring &r, int slot_global, int slot_in_stream, int lane) {
+    const char *src = r.w + (size_t)slot_in_stream * SLOT_BYTES + r.wave * (PIECES * 1024) + lane * 16;
+    char *dst = r.lds + (slot_global & (NSLOT - 1)) * SLOT_BYTES + r.wave * (PIECES * 1024);
+    ring_dma<0>(src, dst); ring_dma<1>(src, dst); ring_dma<2>(src, dst); ring_dma<3>(src, dst);
+    if constexpr (PIECES == 8) { ring_dma<4>(src, dst); ring_dma<5>(src, dst); ring_dma<6>(src, dst); ring_dma<7>(src, dst); }
+}
+
+// flags: 1 no DMA, 2 no barrier, 4 no activation, 8 s_setprio 1 for the second half of the waves
+// ================================================================================================= shape A
+template <int FLAGS, int U>
+__device__ __forceinline__ void unitA(Ring &r, int lane, half8 (&ring)[3][4], half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
+                                      const float *bias, int &pos_cur, int &pos_nxt) {
+    constexpr int S = (U % 32) >> 1, HALF = U / 32, IB = 4 * HALF + 2 * (U & 1);
+    if constexpr (U % UPS == 0) {
+        if constexpr (!(FLAGS & 1)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (!(FLAGS & 2)) __builtin_amdgcn_s_barrier();
+        pos_cur = r.g & (NSLOT - 1);
+        pos_nxt = (pos_cur + 1) & (NSLOT - 1);
+        if constexpr (!(FLAGS & 1)) ring_issue<8>(r, r.g + 3, r.next, lane);
+        r.next = r.next + 1 == STREAM_SLOTS ? 0 : r.next + 1;
+        r.g++;
+    }
+    constexpr int UN = U + 2;
+    const unsigned pf = r.lds_lane + ((UN / UPS) == (U / UPS) ? pos_cur : pos_nxt) * SLOT_BYTES;
+    // activation: half a fragment per unit during units 0..15 (pending lower half of the previous layer -> fragments 8..15) and
+    // 48..63 (own upper half -> fragments 0..7), as in mlp_kernel
+    constexpr bool ACT = !(FLAGS & 4) && (U < 16 || U >= 48);
+    constexpr int T = U < 16 ? 8 + U / 2 : (U - 48) / 2, HS = U % 2, AIB = T / 2, Q = T % 2;
+    half8(&a)[4] = ring[U % 3];
+    half8(&nx)[4] = ring[UN % 3];
+    Act g;
+    unsigned hi[2], lo[2];
+    lds_wait<4>();
+    if constexpr (ACT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g.b) : "v"(lds_addr(bias) + (lane >> 5) * 16), "n"((U % 16) * 64));
+    float v[4];
+#define GAP(K) \
+    if constexpr (ACT) { if constexpr (K == 0) { for (int e = 0; e < 4; e++) v[e] = acc[AIB][8 * Q + 4 * HS + e]; } act_stage<K>(v, g, hi, lo); } \
+    if constexpr (K < 4) ds_read16<(UN % UPS) * 4096 + K * 1024>(nx[K], pf); \
+    __builtin_amdgcn_sched_barrier(0);
+    acc[IB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bh[S], acc[IB], 0, 0, 0);
+    GAP(0)
+    acc[IB + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bh[S], acc[IB + 1], 0, 0, 0);
+    GAP(1)
+    acc[IB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], bh[S], acc[IB], 0, 0, 0);
+    GAP(2)
+    acc[IB + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[3], bh[S], acc[IB + 1], 0, 0, 0);
+    GAP(3)
+    acc[IB] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], bl[S], acc[IB], 0, 0, 0);
+    GAP(4)
+    acc[IB + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[2], bl[S], acc[IB + 1], 0, 0, 0);
+    GAP(5)
+#undef GAP
+    if constexpr (ACT) { put<HS>(bh[T], hi); put<HS>(bl[T], lo); }
+}
+
+template <int FLAGS, int... Us>
+__device__ __forceinline__ void unitsA(std::integer_sequence<int, Us...>, Ring &r, int lane, half8 (&ring)[3][4], half8 (&bh)[16],
+                                       half8 (&bl)[16], f32x16 (&acc)[8], const float *bias, int &pc, int &pn) {
+    (unitA<FLAGS, Us>(r, lane, ring, bh, bl, acc, bias, pc, pn), ...);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 1) void shapeA(float *out, const half8 *in, const char *w, int layers) {
+    __shared__ __attribute__((aligned(1024))) char lds[NSLOT * SLOT_BYTES + 4096];
+    const int lane = threadIdx.x & 63;
+    Ring r{w, 0, 3, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), 8, lds_addr(lds) + lane * 16, lds};
+    float *bias = reinterpret_cast<float *>(lds + NSLOT * SLOT_BYTES);
+    for (int i = threadIdx.x; i < 1024; i += 256) bias[i] = 0.001f * i;
+    __syncthreads();
+    for (int s = 0; s < 3; s++) ring_issue<8>(r, s, s, lane);
+    half8 bh[16], bl[16], ring[3][4];
+    f32x16 acc[8];
+    for (int s = 0; s < 16; s++) { bh[s] = in[lane + 64 * s]; bl[s] = in[lane + 64 * (16 + s)]; }
+    for (int i = 0; i < 8; i++) for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
+    int pc = 0, pn = 1;
+#pragma unroll 1
+    for (int l = 0; l < layers; l++) {
+        // the first two units' fragments (the register ring runs two units ahead inside a layer)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned q = r.lds_lane + (r.g & (NSLOT - 1)) * SLOT_BYTES;
+        ds_read16<0>(ring[0][0], q); ds_read16<1024>(ring[0][1], q); ds_read16<2048>(ring[0][2], q); ds_read16<3072>(ring[0][3], q);
+        ds_read16<4096>(ring[1][0], q); ds_read16<5120>(ring[1][1], q); ds_read16<6144>(ring[1][2], q); ds_read16<7168>(ring[1][3], q);
+        unitsA<FLAGS>(std::make_integer_sequence<int, 64>{}, r, lane, ring, bh, bl, acc, bias, pc, pn);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float s = 0.f;
+    for (int i = 0; i < 8; i++) for (int e = 0; e < 16; e++) s += acc[i][e];
+    for (int i = 0; i < 16; i++) s += (float)bh[i][0] + (float)bl[i][1];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// ================================================================================================= shape B
+// 16 samples per wave: accumulators 16 row blocks x f32x4, B fragments 8 k-steps of 32 (hi, lo).  Unit = one k-step of a pair of
+// 16-row blocks: 4 weight fragments (rb, hi) (rb, lo) (rb+1, hi) (rb+1, lo), 6 MFMAs of 16 cycles.  Unit order as in shape A: the
+// upper half of the outputs (row blocks 0..7) for all 8 k-steps, then the lower half: U -> HALF = U / 32, S = (U % 32) / 4,
+// row-block pair (U % 4) of the half.  Activation: 4 values per stage = one row block's 4 rows of this lane = half of a B
+// fragment (fragment t <- row blocks 2t, 2t+1): 16 stages of the pending lower half (fragments 4..7) in units 0..15, 16 of the
+// own upper half (fragments 0..3) in units 48..63.
+template <int FLAGS, int U>
+__device__ __forceinline__ void unitB(Ring &r, int lane, half8 (&ring)[3][4], half8 (&bh)[8], half8 (&bl)[8], f32x4 (&acc)[16],
+                                      const float *bias, int &pos_cur, int &pos_nxt) {
+    constexpr int S = (U % 32) >> 2, HALF = U / 32, RB = 8 * HALF + 2 * (U & 3);
+    if constexpr (U % UPS == 0) {
+        if constexpr (!(FLAGS & 1)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (!(FLAGS & 2)) __builtin_amdgcn_s_barrier();
+        pos_cur = r.g & (NSLOT - 1);
+        pos_nxt = (pos_cur + 1) & (NSLOT - 1);
+        if constexpr (!(FLAGS & 1)) ring_issue<4>(r, r.g + 3, r.next, lane);
+        r.next = r.next + 1 == STREAM_SLOTS ? 0 : r.next + 1;
+        r.g++;
+    }
+    constexpr int UN = U + 2;
+    const unsigned pf = r.lds_lane + ((UN / UPS) == (U / UPS) ? pos_cur : pos_nxt) * SLOT_BYTES;
+    constexpr bool ACT = !(FLAGS & 4) && (U < 16 || U >= 48);
+    constexpr int A = U < 16 ? U : U - 48;                 // stage index 0..15
+    constexpr int T = (U < 16 ? 4 : 0) + A / 4, HS = (A / 2) % 2, ARB = (U < 16 ? 8 : 0) + A;   // fragment, half, source row block
+    half8(&a)[4] = ring[U % 3];
+    half8(&nx)[4] = ring[UN % 3];
+    Act g;
+    unsigned hi[2], lo[2];
+    lds_wait<4>();
+    if constexpr (ACT) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(g.b) : "v"(lds_addr(bias) + (lane >> 4) * 16), "n"((U % 16) * 64));
+    float v[4];
+#define GAP(K) \
+    if constexpr (ACT) { if constexpr (K == 0) { for (int e = 0; e < 4; e++) v[e] = acc[ARB][e]; } act_stage<K>(v, g, hi, lo); } \
+    if constexpr (K < 4) ds_read16<(UN % UPS) * 4096 + K * 1024>(nx[K], pf); \
+    __builtin_amdgcn_sched_barrier(0);
+    acc[RB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bh[S], acc[RB], 0, 0, 0);
+    GAP(0)
+    acc[RB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2], bh[S], acc[RB + 1], 0, 0, 0);
+    GAP(1)
+    acc[RB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], bh[S], acc[RB], 0, 0, 0);
+    GAP(2)
+    acc[RB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[3], bh[S], acc[RB + 1], 0, 0, 0);
+    GAP(3)
+    acc[RB] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bl[S], acc[RB], 0, 0, 0);
+    GAP(4)
+    acc[RB + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[2], bl[S], acc[RB + 1], 0, 0, 0);
+    GAP(5)
+#undef GAP
+    if constexpr (ACT) { put<HS>(bh[T], hi); put<HS>(bl[T], lo); }
+}
+
+template <int FLAGS, int... Us>
+__device__ __forceinline__ void unitsB(std::integer_sequence<int, Us...>, Ring &r, int lane, half8 (&ring)[3][4], half8 (&bh)[8],
+                                       half8 (&bl)[8], f32x4 (&acc)[16], const float *bias, int &pc, int &pn) {
+    (unitB<FLAGS, Us>(r, lane, ring, bh, bl, acc, bias, pc, pn), ...);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(512, 2) void shapeB(float *out, const half8 *in, const char *w, int layers) {
+    __shared__ __attribute__((aligned(1024))) char lds[NSLOT * SLOT_BYTES + 4096];
+    const int lane = threadIdx.x & 63;
+    Ring r{w, 0, 3, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), 4, lds_addr(lds) + lane * 16, lds};
+    float *bias = reinterpret_cast<float *>(lds + NSLOT * SLOT_BYTES);
+    for (int i = threadIdx.x; i < 1024; i += 512) bias[i] = 0.001f * i;
+    __syncthreads();
+    if constexpr (FLAGS & 8) { if (r.wave >= 4) __builtin_amdgcn_s_setprio(1); }
+    for (int s = 0; s < 3; s++) ring_issue<4>(r, s, s, lane);
+    half8 bh[8], bl[8], ring[3][4];
+    f32x4 acc[16];
+    for (int s = 0; s < 8; s++) { bh[s] = in[lane + 64 * s]; bl[s] = in[lane + 64 * (16 + s)]; }
+    for (int i = 0; i < 16; i++) for (int e = 0; e < 4; e++) acc[i][e] = 0.f;
+    int pc = 0, pn = 1;
+#pragma unroll 1
+    for (int l = 0; l < layers; l++) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned q = r.lds_lane + (r.g & (NSLOT - 1)) * SLOT_BYTES;
+        ds_read16<0>(ring[0][0], q); ds_read16<1024>(ring[0][1], q); ds_read16<2048>(ring[0][2], q); ds_read16<3072>(ring[0][3], q);
+        ds_read16<4096>(ring[1][0], q); ds_read16<5120>(ring[1][1], q); ds_read16<6144>(ring[1][2], q); ds_read16<7168>(ring[1][3], q);
+        unitsB<FLAGS>(std::make_integer_sequence<int, 64>{}, r, lane, ring, bh, bl, acc, bias, pc, pn);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float s = 0.f;
+    for (int i = 0; i < 16; i++) for (int e = 0; e < 4; e++) s += acc[i][e];
+    for (int i = 0; i < 8; i++) s += (float)bh[i][0] + (float)bl[i][1];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <typename K>
+static void run(const char *name, K kernel, int threads, float *out, half8 *in, char *w) {
+    const int layers = 600;
+    hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), 0, 0, out, in, w, 50);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(kernel, dim3(256), dim3(threads), 0, 0, out, in, w, layers);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        best = ms < best ? ms : best;
+    }
+    const double us_layer = best * 1e3 / layers;
+    // 128 samples per CU and layer; 2 * 256 * 256 FLOP per sample and layer (algorithmic), x3 issued
+    printf("%-34s %8.3f us per layer  -> %6.1f TFLOP/s algorithmic on 256 CUs (%5.1f %% of 12288 cycles @2.4 GHz)\n", name, us_layer,
+           128.0 * 2 * 256 * 256 * 256 / us_layer * 1e-6, 100.0 * 12288 / 2.4e3 / us_layer);
+}
+
+int main() {
+    float *out; half8 *in; char *w;
+    hipMalloc(&out, 256 * 512 * 4);
+    hipMalloc(&in, 64 * 32 * 16);
+    hipMalloc(&w, (size_t)STREAM_SLOTS * SLOT_BYTES);
+    // random-ish bit patterns (zeros clock higher: DVFS)
+    {
+        std::vector<unsigned short> h((size_t)STREAM_SLOTS * SLOT_BYTES / 2);
+        unsigned x = 12345u;
+        for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3000u | ((x >> 16) & 0x0fffu) | ((x >> 3) & 0x8000u)); }
+        hipMemcpy(w, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        hipMemcpy(in, h.data(), 64 * 32 * 16, hipMemcpyHostToDevice);
+    }
+    run("A 4 waves x 32 samples, 32x32x16", shapeA<0>, 256, out, in, w);
+    run("B 8 waves x 16 samples, 16x16x32", shapeB<0>, 512, out, in, w);
+    run("B + setprio(second half)", shapeB<8>, 512, out, in, w);
+    run("A no activation", shapeA<4>, 256, out, in, w);
+    run("B no activation", shapeB<4>, 512, out, in, w);
+    run("A no DMA / barrier", shapeA<3>, 256, out, in, w);
+    run("B no DMA / barrier", shapeB<3>, 512, out, in, w);
+    run("A MFMA + fragment reads only", shapeA<7>, 256, out, in, w);
+    run("B MFMA + fragment reads only", shapeB<7>, 512, out, in, w);
+    return 0;
+}
