@@ -335,3 +335,30 @@ def test_scene_maps_written_like_the_reference(tmp_path, scene256):
     np.testing.assert_array_equal(np.asarray(Image.open(tmp_path / "height_map.png")), height)
     h = scene256.current_height_map[0, 0].numpy()
     np.testing.assert_array_equal(height, ((h * 0.5 + 0.5) * 255).astype(np.uint8))
+
+
+@pytest.mark.needs_reference
+def test_bench_cpu_baseline_reference_leg_equals_the_oracle(scene256, weights_full, lut):
+    """bench.py's cpu_baseline with kind "reference" (the unmodified generator on the reference's own native sources compiled
+    for the host) renders the same pixels as the oracle's tiled frame -- the two legs are interchangeable as a baseline and
+    as the CPU side of the bench line's `precision` record."""
+    import importlib.util
+    from oracle import field_ref as FR
+    from oracle import ref_native
+    from scenedreamer_amd import camera, synth
+    if not ref_native.available():
+        pytest.skip("oracle/_ref not built")
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    z = FR.style_mlp(weights_full, np.asarray(synth.make_style(8888))).numpy()
+    ge = FR.world_encoder(weights_full, scene256.current_height_map, scene256.current_semantic_map).numpy()
+    pose = camera.eval_camera_poses(scene256, maxstep=40)[8]
+    hw, ns, picks = (150, 200), 12, [(0, 0), (1, 1)]
+    t_frame, t_tiles, got = bench._reference_tiles(weights_full, scene256, scene256.voxel_t.numpy(), pose, hw, ns, z, ge, picks)
+    ref = FR.render_frame_tiled(weights_full, lut, scene256.voxel_t.numpy(), (pose[0].numpy(), pose[1].numpy(), pose[2].numpy(), pose[3]),
+                                hw, ns, z, ge, tiles=picks)
+    assert t_frame > 0 and t_tiles > 0 and set(got) == set(ref)
+    for k in picks:
+        assert got[k][:2] == ref[k][:2]
+        assert torch.equal(got[k][2], ref[k][2])
