@@ -27,15 +27,19 @@ BIOME_COLORS = ((255, 255, 178), (184, 200, 98), (188, 161, 53), (190, 255, 242)
                 (34, 61, 53), (35, 114, 94), (0, 0, 255), (0, 255, 0))
 
 
-def write_scene_maps(output_dir, scene):
+def write_scene_maps(output_dir, scene, division="reciprocal"):
     """semantic_map.png (argmax class of current_semantic_map [1,11,S,S] through BIOME_COLORS, RGB) and height_map.png
     (current_height_map [1,1,S,S] as write_img maps it: ((h * 0.5 + 0.5) * 255) truncated to uint8, one channel) --
-    scenedreamer.py:545, :562-563.  Returns the two arrays."""
+    scenedreamer.py:545, :562-563.  Returns the two arrays.
+    division: the reference pushes the colours through a float round trip (`colours / 255 * 2 - 1` at :544, then write_img's
+    `(x * 0.5 + 0.5) * 255` truncated).  `/ 255` on its CUDA tensor is a multiplication by the float32 reciprocal in PyTorch
+    ("reciprocal", default: what the reference writes when it runs on a GPU), on a CPU tensor an IEEE division ("ieee"); three
+    of the 33 colour values come out one level apart."""
     os.makedirs(output_dir, exist_ok=True)
     sem = torch.argmax(torch.as_tensor(scene.current_semantic_map), dim=1)[0].cpu()
-    # the reference pushes the colours through write_img's float round trip (c / 255 * 2 - 1, then (x * 0.5 + 0.5) * 255
-    # truncated): replayed in float32 so that a colour that lands a hair under its integer truncates like there
-    table = (torch.tensor(BIOME_COLORS, dtype=torch.float32) / 255 * 2 - 1)
+    c = np.asarray(BIOME_COLORS, np.float32)
+    c = c * (np.float32(1.0) / np.float32(255.0)) if division == "reciprocal" else c / np.float32(255.0)
+    table = torch.from_numpy(c * np.float32(2) - np.float32(1))
     sem_rgb = ((table[sem] * 0.5 + 0.5) * 255).numpy().astype(np.uint8)
     h = torch.as_tensor(scene.current_height_map)[0, 0].cpu().to(torch.float32)
     height = ((h * 0.5 + 0.5) * 255).numpy().astype(np.uint8)

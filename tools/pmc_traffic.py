@@ -15,8 +15,14 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+# (the render CNN's launches by template instance: <TAPS, DBG, TERMS, EPI>; "conv_kernel<9>" / "<1>" = the first instance that
+# matches, kept for the records of earlier rounds)
 KERNELS = {"mlp_kernel": ("mlp_kernel", 2.0), "encode_kernel": ("encode_kernel", 1.0), "conv_kernel<9>": ("conv_kernel<9", 2.0),
-           "conv_kernel<1>": ("conv_kernel<1", 2.0), "sky_kernel": ("sky_kernel", 2.0), "rvip_kernel": ("rvip_kernel", 1.0)}
+           "conv_kernel<1>": ("conv_kernel<1", 2.0), "sky_kernel": ("sky_kernel", 2.0), "rvip_kernel": ("rvip_kernel", 1.0),
+           "conv_kernel<9, 0, 1, 0> (conv2a/3a)": ("conv_kernel<9, 0, 1, 0>", 2.0),
+           "conv_kernel<9, 0, 1, 27> (conv2b/3b)": ("conv_kernel<9, 0, 1, 27>", 2.0),
+           "conv_kernel<1, 0, 3, 16> (conv1/conv4a)": ("conv_kernel<1, 0, 3, 16>", 2.0),
+           "conv_kernel<1, 0, 3, 255> (conv4b + conv4)": ("conv_kernel<1, 0, 3, 255>", 2.0)}
 
 
 def counters(path):
