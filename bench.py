@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--volume", default="compact", choices=["compact", "int32"],
                     help="scene volume the rays walk: uint8 palette indices + int32 palette (scene.py, 4x smaller, what the "
                          "ranks receive; voxel ids come out identical) or the reference's int32 block ids")
+    ap.add_argument("--backend", default=os.environ.get("SDN_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="torch.distributed backend for --gpus N > 1: nccl (= RCCL over xGMI, one GPU per rank: the production path) "
+                         "or gloo (collectives staged through host memory by scenedreamer_amd.dist; lets N ranks share one GPU, "
+                         "which is how this script's multi-rank path is exercised on a one-GPU box -- timings are then meaningless)")
     ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
                     help="BASELINE.json configs[i-1]: sets resolution / samples / cam_maxstep / bench mode / steps")
     args = ap.parse_args()
@@ -216,12 +220,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    ndev = torch.cuda.device_count()
+    if local >= ndev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible (RCCL needs one GPU per rank; --backend gloo shares GPUs)")
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", init_method="env://")
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        dist.init_process_group(args.backend, init_method="env://")
 
     from scenedreamer_amd import camera, capi, synth
     from scenedreamer_amd import dist as sdist
@@ -304,7 +311,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sdist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     frame_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
@@ -397,6 +404,7 @@ def main():
                        "field_rays": (hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30),
                        "samples_per_frame": ((hw[0] + 8) * (hw[1] + 8) if (args.apron == "minimal" and mode == "fused") else (hw[0] + 30) * (hw[1] + 30)) * args.samples,
                        "parallelism": f"row bands x{world}" if tile_parallel else f"frames x{world}",
+                       "dist_backend": (args.backend + (f", {world} ranks on {ndev} GPU(s)" if world > ndev else "")) if world > 1 else None,
                        "apron_note": "ray casting and the sky MLP always cover the reference's padded frame (15-px apron); "
                                      "'minimal' evaluates the field MLP and the CNN on the 4-px apron that can reach a kept "
                                      "pixel -- the image is bit-identical (tests/test_render_gpu.py, test_fullsize_gpu.py)"},

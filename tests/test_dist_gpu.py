@@ -149,3 +149,30 @@ def test_rccl_backend_accepts_every_collective_dist_uses():
     p.join(60)
     assert status == "ok", info
     assert len(info) == 4 and p.exitcode == 0
+
+
+@pytest.mark.parametrize("bench_mode", ["frames", "tile-parallel"])
+def test_bench_py_multi_rank_path_two_ranks_on_one_gpu(bench_mode):
+    """bench.py exactly as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N ... bench.py
+    --gpus N`), with two ranks sharing the box's one GPU over gloo (`--backend gloo`; the production backend is RCCL with one
+    GPU per rank): state broadcast, the job-wide CNN precision decision, sharded / tile-parallel frames, barriers, MAX over
+    ranks of the elapsed time, ONE JSON line from rank 0.  Small workload: the numbers mean nothing, the path is what is run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--scene-size", "256", "--height", "96", "--width", "136", "--samples", "12", "--no-extras",
+           "--bench-mode", bench_mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["unit"] == "frames/s"
+    assert d["scaling"] == ("strong" if bench_mode == "tile-parallel" else "weak")
+    assert d["config"]["dist_backend"].startswith("gloo, 2 ranks on 1 GPU")
+    assert d["config"]["parallelism"] == ("row bands x2" if bench_mode == "tile-parallel" else "frames x2")
+    if bench_mode == "frames":
+        assert d["broadcast"]["scene_volume_bytes"] > 0 and "cpu_baseline" not in d      # compact volume; no CPU leg at N > 1
