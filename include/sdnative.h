@@ -219,6 +219,20 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
                   int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
                   const float *sky_avg, int32_t *ticket, sdn_stream_t stream);
+/* sdn_field_encode + sdn_field_mlp as ONE kernel (the north star's "trilinear hash-grid lookup plus the tiny sigma/color MLP
+ * fused into one kernel"; replaces Generator._forward_perpix's hash_encoder -> render_net call chain, scenedreamer.py:298-311,
+ * with the sample placement in front of it, :341-363, and the compositing behind it, :373-413): every 4-sample pass of a
+ * 32-ray group starts with its own sample placement and collapsed-table gathers, executed by the wave that then runs the
+ * MLP on them, straight into its MFMA operand registers.  No feature / dist / label / rayflag buffers; net_out is the same
+ * bits as the two-kernel sequence produces.  Arguments: those of sdn_field_encode (inputs) and of sdn_field_mlp (weights,
+ * sky, outputs, schedule) with the same meaning; colour_terms 3 or 6. */
+int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
+                     const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
+                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
+                     int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale,
+                     const void *packed, const float *consts, const float *sky_c, const float *sky_avg, float *net_out,
+                     int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
+                     int32_t strat_division, int32_t *ticket, sdn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Render CNN: the convolutions of RenderCNN (imaginaire/generators/gancraft_base.py:175-225, forward :202-225) on MFMA

@@ -58,6 +58,9 @@ _SIGNATURES = {
                                ctypes.c_int32, c_p]),
     "sdn_field_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                             ctypes.c_float, c_p, ctypes.c_int32, c_p, c_p, c_p, c_p]),
+    "sdn_field_render": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
+                               ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, c_f, c_p, ctypes.c_int32, c_p,
+                               ctypes.c_int32, c_p, c_p]),
     "sdn_sky_packed_weight_bytes": (ctypes.c_size_t, []),
     "sdn_sky_consts_floats": (ctypes.c_size_t, []),
     "sdn_sky_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),

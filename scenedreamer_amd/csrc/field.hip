@@ -39,6 +39,11 @@
 //                     Volume rendering, the density head, label bias, clamp and sky blend run in the
 //                     epilogues on the VALU.  The persistent workgroups draw their 32-ray groups from a
 //                     ticket counter; groups whose rays all miss are skipped.
+//   field_kernel      = mlp_kernel<.., FUSED>: the north star's "hash-grid lookup plus the MLP fused into ONE kernel".  Every
+//                     pass starts with the encode stage of its own 32 samples (sample placement + collapsed-table gathers,
+//                     the very device functions encode_kernel is made of) executed by the MLP wave into its B-fragment
+//                     registers -- a lane's 8 levels x 8 channels ARE its 8 B fragments, so nothing is exchanged -- while the
+//                     accumulator / fragment-ring registers are dead.  No feature buffer, no 10.8 GB HBM round trip.
 //   sky_kernel        the same machinery for SKYMLP on every ray of the padded frame + the frame mean.
 #include <hip/hip_fp16.h>
 
@@ -137,6 +142,7 @@ struct MlpParams {
     int32_t *ticket;           // optional dev int32[2], zero before the first launch (the kernel leaves it zero): the
                                // persistent workgroups draw their 32-ray groups from it instead of taking every
                                // gridDim.x-th one (a static share that is mostly sky leaves its workgroup idle at the end)
+    EncParams enc;             // FUSED (field_kernel): the encode stage's inputs; feat / dist / label / rayflag are unused then
 };
 
 // =====================================================================================================
@@ -434,6 +440,132 @@ __device__ __forceinline__ float normalise_coord(float wc, float delim) {
     return n / 2.f;
 }
 
+// ---- the per-sample steps of the encode stage, shared by encode_kernel (features handed to mlp_kernel through HBM) and by
+// ---- field_kernel = mlp_kernel<.., FUSED> (the same steps at the start of every pass: lookup + MLP in ONE kernel) ------------
+// Lane (h = lane >> 5, j = lane & 31) of a wave that owns ray tile `tile` works on ray tile * 8 + (j >> 2), sample
+// 4 * ch + (j & 3) of pass ch, and on the levels 2 * s + h, s = 0..7: its 8 x 8 blended values ARE B fragment s of the MLP.
+__device__ __forceinline__ void enc_load_ray(const EncParams &p, int rr, RayBoxes &rb, float (&d)[3]) {
+    const size_t RS = (size_t)p.win.n_src;
+#pragma unroll
+    for (int k = 0; k < MAXM; k++) {
+        if (k < p.M) {
+            rb.t[k] = p.depth2[(size_t)rr * p.M + k];
+            rb.t2[k] = p.depth2[(RS + rr) * p.M + k];
+            rb.id[k] = p.voxel_id[(size_t)rr * p.M + k];
+        } else {
+            rb.t[k] = rb.t2[k] = __builtin_nanf("");
+            rb.id[k] = 0;
+        }
+    }
+    d[0] = p.raydirs[(size_t)rr * 3]; d[1] = p.raydirs[(size_t)rr * 3 + 1]; d[2] = p.raydirs[(size_t)rr * 3 + 2];
+}
+
+struct EncSample {
+    float x0, x1, x2;     // grid coordinates in [0, 1]
+    bool oob, valid, gnd; // outside the grid / a real sample of a real ray / world x <= 1 (scenedreamer.py:380)
+    float dist;           // new_dists * dists_scale (0 for padding samples)
+    int label;            // reduced label of the box the sample falls into
+};
+
+__device__ __forceinline__ EncSample enc_place(const EncParams &p, const RayBoxes &rb, const float (&d)[3], int rl, int sidx, bool ray_ok) {
+    EncSample e;
+    e.valid = ray_ok && sidx < p.ns;
+    const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)rl * (p.ns + 1) : nullptr, p.ieee_div ? -(p.ns + 1) : p.ns + 1,
+                                   e.valid ? sidx : 0, p.sample_depth);
+    const float wx = mul_add_exact(d[0], pl.depth, p.ori[0]);  // scenedreamer.py:354
+    const float wy = mul_add_exact(d[1], pl.depth, p.ori[1]);
+    const float wz = mul_add_exact(d[2], pl.depth, p.ori[2]);
+    e.gnd = e.valid && wx <= 1.0f;                           // :380
+    e.x0 = normalise_coord(wx, p.delim[0]);
+    e.x1 = normalise_coord(wy, p.delim[1]);
+    e.x2 = normalise_coord(wz, p.delim[2]);
+    e.oob = p.genc_oob || e.x0 < 0.f || e.x0 > 1.f || e.x1 < 0.f || e.x1 > 1.f || e.x2 < 0.f || e.x2 > 1.f;
+    e.dist = e.valid ? pl.dist * p.dists_scale : 0.f;
+    int id = rb.id[0];
+#pragma unroll
+    for (int k = 1; k < MAXM; k++)
+        if (k == pl.idx) id = rb.id[k];
+    e.label = p.lut[id & 1023];
+    return e;
+}
+
+// The 8 blended channels of one level = 8 corners of the collapsed 3-D table, in three steps so that a caller can put the
+// gathers of SEVERAL levels in flight before it blends any of them (field_kernel: one wave per SIMD has no other wave to hide
+// a level's round trip behind): where the rows are, the rows, the blend in the reference's multiply order.
+struct LevelAddr {
+    float f0, f1, f2;       // fractional position inside the cell
+    const float *row[8];    // corner c: bit d of c = +1 on dimension d
+};
+
+__device__ __forceinline__ void enc_level_addr(const EncParams &p, const EncSample &e, int level, bool ok, LevelAddr &a) {
+    const float scale = p.scales[level];
+    float f0 = mul_add_exact(e.x0, scale, 0.5f), f1 = mul_add_exact(e.x1, scale, 0.5f), f2 = mul_add_exact(e.x2, scale, 0.5f);
+    const float g0 = floorf(f0), g1 = floorf(f1), g2 = floorf(f2);
+    a.f0 = f0 - g0; a.f1 = f1 - g1; a.f2 = f2 - g2;
+    const uint32_t a0 = (uint32_t)g0, a1 = (uint32_t)g1 * 2654435761u, a2 = (uint32_t)g2 * 805459861u;
+    const uint32_t b0 = a0 + 1u, b1 = a1 + 2654435761u, b2 = a2 + 805459861u;
+    const float *tb = p.table3 + (size_t)level * ((size_t)p.tmask + 1) * 8;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const uint32_t hsh = ((c & 1) ? b0 : a0) ^ ((c & 2) ? b1 : a1) ^ ((c & 4) ? b2 : a2);
+        a.row[c] = tb + (size_t)(ok ? (hsh & p.tmask) : 0u) * 8;     // (lanes without a sample read row 0 and discard it)
+    }
+}
+
+__device__ __forceinline__ void enc_level_load(const LevelAddr &a, float4 (&va)[8], float4 (&vb)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        va[c] = *reinterpret_cast<const float4 *>(a.row[c]);
+        vb[c] = *reinterpret_cast<const float4 *>(a.row[c] + 4);
+    }
+}
+
+__device__ __forceinline__ void enc_level_blend(const LevelAddr &a, const float4 (&va)[8], const float4 (&vb)[8], float (&res)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) res[c] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        float w = 1.f;  // same multiply order as gridencoder.cu:152-160
+        w *= (c & 1) ? a.f0 : 1.f - a.f0;
+        w *= (c & 2) ? a.f1 : 1.f - a.f1;
+        w *= (c & 4) ? a.f2 : 1.f - a.f2;
+        res[0] += w * va[c].x; res[1] += w * va[c].y; res[2] += w * va[c].z; res[3] += w * va[c].w;
+        res[4] += w * vb[c].x; res[5] += w * vb[c].y; res[6] += w * vb[c].z; res[7] += w * vb[c].w;
+    }
+}
+
+// one level at a time (encode_kernel: its other waves hide the round trip); no loads at all for lanes without a sample
+__device__ __forceinline__ void enc_level(const EncParams &p, const EncSample &e, int level, bool use_feat, float (&res)[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) res[c] = 0.f;
+    if (!e.oob && e.valid && use_feat) {
+        LevelAddr a;
+        float4 va[8], vb[8];
+        enc_level_addr(p, e, level, true, a);
+        enc_level_load(a, va, vb);
+        enc_level_blend(a, va, vb, res);
+    }
+}
+
+// NB levels 2 * (S0 + t) + h, t = 0 .. NB-1, with all their gathers issued before the first blend (branch-free: lanes without
+// a sample gather row 0 and get zeros by selection).  The arithmetic of a lane that has a sample is enc_level's, bit for bit.
+template <int NB>
+__device__ __forceinline__ void enc_levels(const EncParams &p, const EncSample &e, int s0, int h, bool use_feat, float (&res)[NB][8]) {
+    const bool ok = !e.oob && e.valid && use_feat;
+    LevelAddr a[NB];
+    float4 va[NB][8], vb[NB][8];
+#pragma unroll
+    for (int t = 0; t < NB; t++) enc_level_addr(p, e, 2 * (s0 + t) + h, ok, a[t]);
+#pragma unroll
+    for (int t = 0; t < NB; t++) enc_level_load(a[t], va[t], vb[t]);
+#pragma unroll
+    for (int t = 0; t < NB; t++) {
+        enc_level_blend(a[t], va[t], vb[t], res[t]);
+#pragma unroll
+        for (int c = 0; c < 8; c++) res[t][c] = ok ? res[t][c] : 0.f;
+    }
+}
+
 #ifndef SDN_ENC_OCC
 #define SDN_ENC_OCC 1
 #endif
@@ -446,21 +578,10 @@ __global__ __launch_bounds__(256, SDN_ENC_OCC) void encode_kernel(const EncParam
     const bool ray_ok = ray < p.R;
     const int rl = ray_ok ? ray : p.R - 1;      // local ray (index into u / rayflag)
     const int rr = p.win.src(rl);               // the same ray in the source arrays
-    const size_t RS = (size_t)p.win.n_src;
 
     RayBoxes rb;
-#pragma unroll
-    for (int k = 0; k < MAXM; k++) {
-        if (k < p.M) {
-            rb.t[k] = p.depth2[(size_t)rr * p.M + k];
-            rb.t2[k] = p.depth2[(RS + rr) * p.M + k];
-            rb.id[k] = p.voxel_id[(size_t)rr * p.M + k];
-        } else {
-            rb.t[k] = rb.t2[k] = __builtin_nanf("");
-            rb.id[k] = 0;
-        }
-    }
-    const float d0 = p.raydirs[(size_t)rr * 3], d1 = p.raydirs[(size_t)rr * 3 + 1], d2 = p.raydirs[(size_t)rr * 3 + 2];
+    float d[3];
+    enc_load_ray(p, rr, rb, d);
     bool gnd = false;
     // A ray that hits nothing gets weight 0 for all its samples (scenedreamer.py:376: weights * (1 - sky_only)), so
     // its features are never used: no gathers for its lanes, and no feature traffic at all for a tile of 8 such rays
@@ -469,61 +590,19 @@ __global__ __launch_bounds__(256, SDN_ENC_OCC) void encode_kernel(const EncParam
     const bool tile_dead = !__any(use_feat);
 
     for (int ch = 0; ch < p.nch; ch++) {
-        const int sidx = ch * SAMP_PER_STEP + (j & 3);
-        const bool valid = ray_ok && sidx < p.ns;
-        const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)rl * (p.ns + 1) : nullptr, p.ieee_div ? -(p.ns + 1) : p.ns + 1, valid ? sidx : 0,
-                                       p.sample_depth);
-        const float wx = mul_add_exact(d0, pl.depth, p.ori[0]);  // scenedreamer.py:354
-        const float wy = mul_add_exact(d1, pl.depth, p.ori[1]);
-        const float wz = mul_add_exact(d2, pl.depth, p.ori[2]);
-        if (valid && wx <= 1.0f) gnd = true;                    // :380
-        const float x0 = normalise_coord(wx, p.delim[0]);
-        const float x1 = normalise_coord(wy, p.delim[1]);
-        const float x2 = normalise_coord(wz, p.delim[2]);
-        const bool oob = p.genc_oob || x0 < 0.f || x0 > 1.f || x1 < 0.f || x1 > 1.f || x2 < 0.f || x2 > 1.f;
-
+        const EncSample e = enc_place(p, rb, d, rl, ch * SAMP_PER_STEP + (j & 3), ray_ok);
+        if (e.gnd) gnd = true;
         const size_t tc = (size_t)tile * p.nch + ch;
         if (h == 0) {
-            p.dist[tc * 32 + j] = valid ? pl.dist * p.dists_scale : 0.f;
-            int id = rb.id[0];
-#pragma unroll
-            for (int k = 1; k < MAXM; k++)
-                if (k == pl.idx) id = rb.id[k];
-            p.label[tc * 32 + j] = p.lut[id & 1023];
+            p.dist[tc * 32 + j] = e.dist;
+            p.label[tc * 32 + j] = (uint8_t)e.label;
         }
         if (tile_dead) continue;
         float *fout = p.feat + (tc * 8 * 64 + lane) * 8;
 #pragma unroll 2
         for (int s = 0; s < 8; s++) {
-            const int level = 2 * s + h;
-            float res[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (!oob && valid && use_feat) {
-                const float scale = p.scales[level];
-                float f0 = mul_add_exact(x0, scale, 0.5f), f1 = mul_add_exact(x1, scale, 0.5f),
-                      f2 = mul_add_exact(x2, scale, 0.5f);
-                const float g0 = floorf(f0), g1 = floorf(f1), g2 = floorf(f2);
-                f0 -= g0; f1 -= g1; f2 -= g2;
-                const uint32_t a0 = (uint32_t)g0, a1 = (uint32_t)g1 * 2654435761u, a2 = (uint32_t)g2 * 805459861u;
-                const uint32_t b0 = a0 + 1u, b1 = a1 + 2654435761u, b2 = a2 + 805459861u;
-                const float *tb = p.table3 + (size_t)level * ((size_t)p.tmask + 1) * 8;
-                float4 va[8], vb[8];
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const uint32_t hsh = ((c & 1) ? b0 : a0) ^ ((c & 2) ? b1 : a1) ^ ((c & 4) ? b2 : a2);
-                    const float *row = tb + (size_t)(hsh & p.tmask) * 8;
-                    va[c] = *reinterpret_cast<const float4 *>(row);
-                    vb[c] = *reinterpret_cast<const float4 *>(row + 4);
-                }
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    float w = 1.f;  // same multiply order as gridencoder.cu:152-160
-                    w *= (c & 1) ? f0 : 1.f - f0;
-                    w *= (c & 2) ? f1 : 1.f - f1;
-                    w *= (c & 4) ? f2 : 1.f - f2;
-                    res[0] += w * va[c].x; res[1] += w * va[c].y; res[2] += w * va[c].z; res[3] += w * va[c].w;
-                    res[4] += w * vb[c].x; res[5] += w * vb[c].y; res[6] += w * vb[c].z; res[7] += w * vb[c].w;
-                }
-            }
+            float res[8];
+            enc_level(p, e, 2 * s + h, use_feat, res);
             float *o = fout + (size_t)s * 64 * 8;
             // The features leave as the MLP's operands: the 8 values of this lane's B fragment split into f16 hi (first
             // 16 bytes) and f16 lo (second 16 bytes) -- the same 32 bytes per lane and k-step as 8 floats, and exactly the
@@ -629,7 +708,11 @@ constexpr int SLOTS_PER_PASS = (8 + 5 * 16 + 4) * 4 / UNITS_PER_SLOT;   // 46
 constexpr int LDS_RING = 0;
 constexpr int LDS_CONST = NSLOT * SLOT_BYTES;     // fp32 constant block
 constexpr int LDS_FLAGS = LDS_CONST + ((C_TOTAL * 4 + 255) / 256) * 256;
-constexpr int LDS_TOTAL = LDS_FLAGS + 64;
+// field_kernel only: the encode stage's small tables, so that a pass's sample placement waits for no dependent global load
+constexpr int LDS_ENC_SCALES = LDS_FLAGS + 64;              // f32 [16]   per-level scales
+constexpr int LDS_ENC_LIN = LDS_ENC_SCALES + NLEV * 4;      // f32 [MAX_LIN] stratified positions
+constexpr int LDS_ENC_LUT = LDS_ENC_LIN + MAX_LIN * 4;      // u8 [1024]  block id -> reduced label
+constexpr int LDS_TOTAL = LDS_ENC_LUT + 1024;
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const char glb_char;
@@ -1334,7 +1417,9 @@ __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], h
 }
 
 // CT = number of split terms of the colour layers fc_5 / fc_6 (3, or 2 = without the Whi.Xlo products)
-template <int DBG, int CT>
+// FUSED = the encode stage runs inside this kernel (field_kernel): a pass's B fragments, distances and labels come from
+//         enc_place / enc_level instead of the feature buffer, the ray flags from the intersections themselves
+template <int DBG, int CT, bool FUSED = false>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1347,6 +1432,16 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     static_assert(C_SKY_AVG + OUTC == C_TOTAL, "sky_avg is the tail of the constant block");
     for (int i = threadIdx.x; i < C_TOTAL; i += 256)
         cst[i] = (p.sky_avg && i >= C_SKY_AVG) ? p.sky_avg[i - C_SKY_AVG] : p.consts[i];
+    // FUSED: the encode stage reads its tables from LDS (a copy of the parameter block with the three pointers redirected)
+    EncParams enc = p.enc;
+    if constexpr (FUSED) {
+        float *e_scales = reinterpret_cast<float *>(lds + LDS_ENC_SCALES), *e_lin = reinterpret_cast<float *>(lds + LDS_ENC_LIN);
+        uint8_t *e_lut = reinterpret_cast<uint8_t *>(lds + LDS_ENC_LUT);
+        if (threadIdx.x < NLEV) e_scales[threadIdx.x] = p.enc.scales[threadIdx.x];
+        if (threadIdx.x < p.enc.ns + 1) e_lin[threadIdx.x] = p.enc.lin[threadIdx.x];
+        for (int i = threadIdx.x; i < 1024; i += 256) e_lut[i] = p.enc.lut[i];
+        enc.scales = e_scales; enc.lin = e_lin; enc.lut = e_lut;
+    }
     __syncthreads();
 
     Ring r;
@@ -1391,7 +1486,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         const bool tile_ok_s = tile_s < p.n_tiles;
         const int ray = tile * RAYS_PER_TILE + (j >> 2);
         const bool ray_ok = tile_ok && ray < p.R;
-        const uint8_t flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
+        const int rl = ray_ok ? ray : p.R - 1;            // FUSED: local ray / the same ray in the frame-wide arrays
+        const int rr = FUSED ? enc.win.src(rl) : 0;
+        uint8_t flag;                                      // bit 0 sky_only, bit 1 nosky (FUSED: bit 1 is known at the group's end)
+        if constexpr (FUSED) flag = (ray_ok && enc.voxel_id[(size_t)rr * enc.M] != 0) ? (uint8_t)0 : (uint8_t)1;   // scenedreamer.py:337
+        else flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
+        bool gnd = false;                                  // FUSED: any sample of the ray at world x <= 1 (:380)
         int drawn = grp_next + (int)gridDim.x;            // the group after next: static stride, or ...
         if (p.ticket && threadIdx.x == 0) drawn = 2 * (int)gridDim.x + atomicAdd(p.ticket, 1);   // ... the next undrawn one
         const bool any_hit = __any(!(flag & 1));
@@ -1427,6 +1527,28 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             int lab;
             float dist;
             float raw[8][8];
+            if constexpr (FUSED) {
+                // ---- the encode stage of THIS pass, by this wave, into its own B-fragment registers (the accumulators, the
+                //      fragment ring and the fp6 state are dead here, so the gathers of several levels can be in flight).
+                //      The loads are ordinary ones: hipcc's own vmcnt waits also retire the ring DMAs issued before them
+                //      (vector memory completes in order) -- a stricter wait than the ring's counted ones, never a wrong one.
+                RayBoxes rb;
+                float dd[3];
+                enc_load_ray(enc, rr, rb, dd);
+                const EncSample es = enc_place(enc, rb, dd, rl, ch * SAMP_PER_STEP + (j & 3), ray_ok);
+                gnd = gnd || es.gnd;
+                lab = es.label;
+                dist = es.dist;
+                const bool use_feat = !(flag & 1);
+                // 4 levels' gathers (64 x 16 B per lane) in flight at a time: two round trips per pass instead of eight
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    float res[4][8];
+                    enc_levels<4>(enc, es, 4 * b, h, use_feat, res);
+#pragma unroll
+                    for (int t = 0; t < 4; t++) split8(res[t], bh[4 * b + t], bl[4 * b + t]);
+                }
+            } else {
             if (pf_tc == tc_s && !(DBG & 256)) {
                 if constexpr (DBG & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -1482,6 +1604,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 bh[s] = __builtin_bit_cast(half8, hw);
                 bl[s] = __builtin_bit_cast(half8, lw);
             }
+            }   // !FUSED
             if constexpr (DBG & 128) {
                 asm volatile("s_waitcnt vmcnt(0)" ::"v"(bh[7]), "v"(bl[7]) : "memory");
                 t_stage += __builtin_readcyclecounter() - t_in0;
@@ -1524,7 +1647,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     tn = (long)tile2 * p.nch;
                 }
                 pf_tc = -1;
-                if (has_next && !(DBG & 256)) {
+                if (!FUSED && has_next && !(DBG & 256)) {
                     pf_tc = tn;
                     const char *base = reinterpret_cast<const char *>(p.feat + ((size_t)tn * 8 * 64 + lane) * 8);
                     // k-steps 2k, 2k+1 (2048 B apart), two 16-B halves each -> a[190+16k : 205+16k]
@@ -1594,6 +1717,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         // ---- blend the sky, store ---------------------------------------------------------------------------------
         tsum += __shfl_xor(tsum, 1);
         tsum += __shfl_xor(tsum, 2);
+        if constexpr (FUSED) {   // nosky = the ray's last intersection is a voxel, or one of its samples lies at world x <= 1 (:335, :382)
+            int g = (int)gnd;
+            g |= __shfl_xor(g, 1);
+            g |= __shfl_xor(g, 2);
+            const bool last_hit = ray_ok && enc.voxel_id[(size_t)rr * enc.M + (enc.M - 1)] != 0;
+            if (last_hit || g) flag |= 2;
+        }
         const bool sky_only = flag & 1, nosky = flag & 2;
         if (sky_only) tsum = 0.f;  // scenedreamer.py:376
         const float sky_w = 1.f - tsum;
@@ -1985,23 +2115,21 @@ static int set_window(RayWindow &w, const int32_t *window_host, int32_t n_rays, 
     return 0;
 }
 
-int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
-                     const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
-                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
-                     int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
-                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, int32_t strat_division,
-                     sdn_stream_t stream) {
-    SDN_REQUIRE(strat_division == 0 || strat_division == 1, "sdn_field_encode: strat_division must be 0 (x * (1/n)) or 1 (x / n)");
-    SDN_REQUIRE(voxel_id && depth2 && raydirs && lut1024 && table3 && scales_dev && genc_host && cam_ori_host &&
-                    voxel_dims_host && lin_dev && feat && dist && label && rayflag,
-                "sdn_field_encode: null pointer");
-    SDN_REQUIRE(n_rays > 0 && num_samples > 0, "sdn_field_encode: empty frame");
-    if (max_blocks < 1 || max_blocks > MAXM) return sdn::fail(SDN_ERR_UNSUPPORTED, "sdn_field_encode: max_blocks must be 1..8");
-    if (num_samples + 1 > MAX_LIN) return sdn::fail(SDN_ERR_UNSUPPORTED, "sdn_field_encode: at most 79 samples per ray");
-    SDN_REQUIRE(table_rows && (table_rows & (table_rows - 1)) == 0, "sdn_field_encode: table_rows must be a power of two");
-    EncParams p;
+// fills the encode-stage parameters (shared by sdn_field_encode and sdn_field_render); outputs / window are set by the caller
+static int fill_enc(EncParams &p, const char *who, const int32_t *voxel_id, const float *depth2, const float *raydirs,
+                    const uint8_t *lut1024, const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
+                    const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev, int32_t n_rays,
+                    int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, int32_t strat_division) {
+    if (!(voxel_id && depth2 && raydirs && lut1024 && table3 && scales_dev && genc_host && cam_ori_host && voxel_dims_host && lin_dev))
+        return sdn::fail(SDN_ERR_INVALID, "%s: null pointer", who);
+    if (!(strat_division == 0 || strat_division == 1))
+        return sdn::fail(SDN_ERR_INVALID, "%s: strat_division must be 0 (x * (1/n)) or 1 (x / n)", who);
+    if (!(n_rays > 0 && num_samples > 0)) return sdn::fail(SDN_ERR_INVALID, "%s: empty frame", who);
+    if (max_blocks < 1 || max_blocks > MAXM) return sdn::fail(SDN_ERR_UNSUPPORTED, "%s: max_blocks must be 1..8", who);
+    if (num_samples + 1 > MAX_LIN) return sdn::fail(SDN_ERR_UNSUPPORTED, "%s: at most 79 samples per ray", who);
+    if (!(table_rows && (table_rows & (table_rows - 1)) == 0)) return sdn::fail(SDN_ERR_INVALID, "%s: table_rows must be a power of two", who);
     p.voxel_id = voxel_id; p.depth2 = depth2; p.raydirs = raydirs; p.lut = lut1024; p.table3 = table3;
-    p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag;
+    p.feat = nullptr; p.dist = nullptr; p.label = nullptr; p.rayflag = nullptr;
     p.R = n_rays; p.M = max_blocks; p.ns = num_samples;
     p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
     p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
@@ -2017,6 +2145,21 @@ int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *
     p.u = u_dev;
     p.ieee_div = strat_division;
     p.scales = scales_dev;
+    return 0;
+}
+
+int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
+                     const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
+                     const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
+                     int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale, float *feat,
+                     float *dist, uint8_t *label, uint8_t *rayflag, const int32_t *window_host, int32_t strat_division,
+                     sdn_stream_t stream) {
+    SDN_REQUIRE(feat && dist && label && rayflag, "sdn_field_encode: null pointer");
+    EncParams p;
+    if (int rc = fill_enc(p, "sdn_field_encode", voxel_id, depth2, raydirs, lut1024, table3, table_rows, scales_dev, genc_host, cam_ori_host,
+                          voxel_dims_host, lin_dev, u_dev, n_rays, max_blocks, num_samples, sample_depth, dists_scale, strat_division))
+        return rc;
+    p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag;
     if (int rc = set_window(p.win, window_host, n_rays, "sdn_field_encode")) return rc;
     hipLaunchKernelGGL(encode_kernel, dim3(sdn::div_up(p.n_tiles, 4)), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_encode");
@@ -2036,27 +2179,43 @@ int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_d
     return sdn::check_launch("sdn_sample_depth");
 }
 
+static int fill_mlp(MlpParams &p, const char *who, const void *packed, const float *consts, const float *sky_c, float *net_out,
+                    int32_t n_rays, int32_t num_samples, int32_t colour_terms, float term_eps, uint8_t *passes, const int32_t *window_host,
+                    const float *sky_avg, int32_t *ticket) {
+    if (!(packed && consts && sky_c && net_out)) return sdn::fail(SDN_ERR_INVALID, "%s: null pointer", who);
+    if (!(n_rays > 0 && num_samples > 0)) return sdn::fail(SDN_ERR_INVALID, "%s: empty frame", who);
+    if (!(colour_terms == 2 || colour_terms == 3 || colour_terms == 6)) return sdn::fail(SDN_ERR_INVALID, "%s: colour_terms must be 2, 3 or 6", who);
+    if (!(term_eps >= 0.f && term_eps < 1.f)) return sdn::fail(SDN_ERR_INVALID, "%s: term_eps must be in [0, 1)", who);
+    p.term_depth = term_eps > 0.f ? -logf(term_eps) : 0.f;
+    p.passes = passes;
+    p.feat = nullptr; p.dist = nullptr; p.label = nullptr; p.rayflag = nullptr;
+    p.wpk = (const half8 *)packed;
+    p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
+    p.sky_avg = sky_avg; p.ticket = ticket;
+    if (int rc = set_window(p.win, window_host, n_rays, who)) return rc;
+    p.R = n_rays; p.ns = num_samples;
+    p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
+    p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
+    return 0;
+}
+
+static int mlp_workgroups(const MlpParams &p, int32_t n_workgroups) {
+    int wg = n_workgroups > 0 ? n_workgroups : 256;
+    const int groups = sdn::div_up(p.n_tiles, 4);
+    return wg > groups ? groups : wg;
+}
+
 int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, const uint8_t *rayflag, const void *packed,
                   const float *consts, const float *sky_c, float *net_out, int32_t n_rays, int32_t num_samples,
                   int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
                   const float *sky_avg, int32_t *ticket, sdn_stream_t stream) {
-    SDN_REQUIRE(feat && dist && label && rayflag && packed && consts && sky_c && net_out, "sdn_field_mlp: null pointer");
-    SDN_REQUIRE(n_rays > 0 && num_samples > 0, "sdn_field_mlp: empty frame");
-    SDN_REQUIRE(colour_terms == 2 || colour_terms == 3 || colour_terms == 6, "sdn_field_mlp: colour_terms must be 2, 3 or 6");
-    SDN_REQUIRE(term_eps >= 0.f && term_eps < 1.f, "sdn_field_mlp: term_eps must be in [0, 1)");
+    SDN_REQUIRE(feat && dist && label && rayflag, "sdn_field_mlp: null pointer");
     MlpParams p;
-    p.term_depth = term_eps > 0.f ? -logf(term_eps) : 0.f;
-    p.passes = passes;
-    p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag; p.wpk = (const half8 *)packed;
-    p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
-    p.sky_avg = sky_avg; p.ticket = ticket;
-    if (int rc = set_window(p.win, window_host, n_rays, "sdn_field_mlp")) return rc;
-    p.R = n_rays; p.ns = num_samples;
-    p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
-    p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
-    int wg = n_workgroups > 0 ? n_workgroups : 256;
-    const int groups = sdn::div_up(p.n_tiles, 4);
-    if (wg > groups) wg = groups;
+    if (int rc = fill_mlp(p, "sdn_field_mlp", packed, consts, sky_c, net_out, n_rays, num_samples, colour_terms, term_eps, passes, window_host,
+                          sky_avg, ticket))
+        return rc;
+    p.feat = feat; p.dist = dist; p.label = label; p.rayflag = rayflag;
+    const int wg = mlp_workgroups(p, n_workgroups);
     static const int dbg = [] {
         const char *e = getenv("SDN_MLP_DBG");   // timing experiments only; results are wrong unless 0
         return e ? atoi(e) : 0;
@@ -2084,6 +2243,28 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
             break;
     }
     return sdn::check_launch("sdn_field_mlp");
+}
+
+int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024, const float *table3,
+                     uint32_t table_rows, const float *scales_dev, const float *genc_host, const float *cam_ori_host,
+                     const float *voxel_dims_host, const float *lin_dev, const float *u_dev, int32_t n_rays, int32_t max_blocks,
+                     int32_t num_samples, float sample_depth, float dists_scale, const void *packed, const float *consts,
+                     const float *sky_c, const float *sky_avg, float *net_out, int32_t colour_terms, float term_eps, uint8_t *passes,
+                     int32_t n_workgroups, const int32_t *window_host, int32_t strat_division, int32_t *ticket, sdn_stream_t stream) {
+    MlpParams p;
+    if (int rc = fill_mlp(p, "sdn_field_render", packed, consts, sky_c, net_out, n_rays, num_samples, colour_terms, term_eps, passes,
+                          window_host, sky_avg, ticket))
+        return rc;
+    if (int rc = fill_enc(p.enc, "sdn_field_render", voxel_id, depth2, raydirs, lut1024, table3, table_rows, scales_dev, genc_host,
+                          cam_ori_host, voxel_dims_host, lin_dev, u_dev, n_rays, max_blocks, num_samples, sample_depth, dists_scale,
+                          strat_division))
+        return rc;
+    p.enc.win = p.win;
+    SDN_REQUIRE(colour_terms != 2, "sdn_field_render: colour_terms must be 3 or 6 (the 2-term profile exists for sdn_field_mlp only)");
+    const int wg = mlp_workgroups(p, n_workgroups);
+    if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((mlp_kernel<0, 3, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_field_render");
 }
 
 size_t sdn_sky_packed_weight_bytes(void) { return SKY_PACKED_FRAGS * sizeof(half8); }

@@ -198,6 +198,63 @@ def mlp_from(R, buf, sky_c, sky_avg, n_rays, ns, window=None):
     return net_out
 
 
+def single_kernel(R):
+    """Whether the field runs as ONE kernel (sdn_field_render: every pass gathers its own features) or as encode_kernel +
+    mlp_kernel with the features handed over through HBM.  Renderer.field_single_kernel, else SDN_FIELD_SINGLE_KERNEL, else
+    the default below."""
+    v = getattr(R, "field_single_kernel", None)
+    if v is None:
+        v = os.environ.get("SDN_FIELD_SINGLE_KERNEL", SINGLE_KERNEL_DEFAULT) not in ("0", "", "false")
+    return bool(v)
+
+
+SINGLE_KERNEL_DEFAULT = "0"
+
+
+def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None, window=None, division="reciprocal",
+                 net_out=None):
+    """The whole field of a ray set in one launch (csrc/field.hip field_kernel): sample placement + hash-grid lookup + render
+    MLP + compositing.  Same arguments and the same bits as field_fused's encode -> mlp sequence; no feature buffer, so no
+    ray chunking at any frame size."""
+    sc = R._fused_scene or prepare_scene(R)
+    st = R._fused_style or prepare_style(R)
+    ct, eps = precision_profile(R)
+    if ct == 2:
+        raise ValueError("the single-kernel field supports colour_terms 3 and 6")
+    if window is None:
+        window = Window(vid.shape[0])
+    n_rays = window.n_rays
+    assert vid.is_contiguous() and d2.is_contiguous() and rd.is_contiguous() and vid.shape[0] == window.n_src
+    sky_c = sky_c.contiguous()
+    sky_avg = torch.as_tensor(sky_avg).reshape(-1).to(device=R.dev, dtype=torch.float32).contiguous()
+    assert sky_avg.numel() == 64 and sky_c.is_cuda and sky_c.device == R.dev and sky_c.shape[0] == window.n_src
+    if net_out is None:
+        net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
+    buf = R.__dict__.setdefault("_fused_lin", {})
+    if u is None:
+        lin = buf.get(("det", ns))
+        if lin is None:
+            lin = buf[("det", ns)] = torch.linspace(0, 1, ns + 3)[1:-1].contiguous().to(R.dev)        # mc_utils.py:120
+    else:
+        assert u.is_cuda and u.dtype == torch.float32 and tuple(u.shape) == (n_rays, ns + 1) and u.is_contiguous()
+        lin = buf.get(("strat", ns))
+        if lin is None:
+            lin = buf[("strat", ns)] = torch.linspace(0, 1, ns + 2)[:-1].contiguous().to(R.dev)      # mc_utils.py:124
+    if "ticket" not in st:
+        st["ticket"] = torch.zeros(2, dtype=torch.int32, device=R.dev)      # the kernel leaves it at zero
+    ori = np.asarray(cam_ori.detach().cpu().numpy() if isinstance(cam_ori, torch.Tensor) else cam_ori, np.float32)
+    with torch.cuda.device(R.dev):
+        rc = _lib().sdn_field_render(vid.data_ptr(), d2.data_ptr(), rd.data_ptr(), sc["lut"].data_ptr(), sc["table3"].data_ptr(),
+                                     sc["T"], sc["scales"].data_ptr(), sc["genc"].ctypes.data, ori.ctypes.data,
+                                     sc["dims"].ctypes.data, lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M,
+                                     ns, R.sample_depth, R.dists_scale, st["packed_mx" if ct == 6 else "packed"].data_ptr(),
+                                     st["consts"].data_ptr(), sky_c.data_ptr(), sky_avg.data_ptr(), net_out.data_ptr(), ct, eps,
+                                     passes.data_ptr() if passes is not None else None, 0, window.host(0),
+                                     {"reciprocal": 0, "ieee": 1}[division], st["ticket"].data_ptr(), _stream(R.dev))
+    capi.check(rc, "sdn_field_render")
+    return net_out
+
+
 def _per_ray_feat_bytes(ns):
     return _lib().sdn_field_feat_bytes(32, ns) // 32
 
@@ -216,6 +273,8 @@ def field_fused(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None
         window = Window(vid.shape[0])
     n_rays = window.n_rays
     vid, d2, rd, sky_c = vid.contiguous(), d2.contiguous(), rd.contiguous(), sky_c.contiguous()
+    if single_kernel(R) and precision_profile(R)[0] != 2:
+        return field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=passes, u=u, window=window, division=division)
     sky_avg = torch.as_tensor(sky_avg).reshape(-1).to(device=R.dev, dtype=torch.float32).contiguous()   # (a host mean is accepted)
     net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
     chunk = max(32, (FEATURE_BUFFER_BYTES // _per_ray_feat_bytes(ns)) // 32 * 32)     # whole 32-ray groups

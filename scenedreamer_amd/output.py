@@ -72,7 +72,7 @@ def open_video(path, fps=10, backend="auto"):
     if backend in ("auto", "imageio"):
         try:
             return _ImageioVideo(path, fps)
-        except ImportError:
+        except (ImportError, AttributeError, NotImplementedError):   # absent, or an inert stand-in without a writer
             if backend == "imageio":
                 raise
     from .mp4 import Mp4MjpegWriter

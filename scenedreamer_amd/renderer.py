@@ -551,7 +551,8 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
     crop = self.pad // 2
     o = crop - CNN_HALO if (apron == "minimal" and crop > CNN_HALO) else 0
     Hp, Wp = cam_res[0] - 2 * o, cam_res[1] - 2 * o
-    deep = mode == "fused" and not kw and fused.single_chunk(Hp * Wp, num_samples)
+    one = mode == "fused" and fused.single_kernel(self) and fused.precision_profile(self)[0] != 2   # lookup + MLP in ONE kernel
+    deep = mode == "fused" and not kw and (one or fused.single_chunk(Hp * Wp, num_samples))
 
     def front(pose, slot):
         start = torch.cuda.Event()
@@ -566,16 +567,20 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
                 vid, d2, rd = vid.view(n0, self.M), d2.view(2, n0, self.M), rd.view(n0, 3)
                 sky_c, sky_avg = fused.sky_fused(self, rd)
                 win = fused.Window.crop(H0, W0, o)      # the kernels read the frame-wide arrays through the window
-                if probe is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(side)
-                buf = fused.encode(self, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), num_samples,
-                                   fused._buffers(self, win.n_rays, num_samples, slot), window=win)
-                if probe is not None:
-                    e1.record(side)
-                    probe.setdefault("encode_kernel", []).append((e0, e1))
-                out = (buf, sky_c, sky_avg, win)
-                keep = (sky_c, sky_avg)     # vid / d2 / rd are only read on the side stream (by encode)
+                if one:     # the field kernel gathers for itself: the front half is ray casting + sky MLP only
+                    out = ((vid, d2, rd), sky_c, sky_avg, win)
+                    keep = (vid, d2, rd, sky_c, sky_avg)
+                else:
+                    if probe is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(side)
+                    buf = fused.encode(self, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), num_samples,
+                                       fused._buffers(self, win.n_rays, num_samples, slot), window=win)
+                    if probe is not None:
+                        e1.record(side)
+                        probe.setdefault("encode_kernel", []).append((e0, e1))
+                    out = (buf, sky_c, sky_avg, win)
+                    keep = (sky_c, sky_avg)     # vid / d2 / rd are only read on the side stream (by encode)
             else:
                 keep = out[:3]
             done = torch.cuda.Event()
@@ -599,7 +604,11 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
             if probe is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(main)
-            net_out = fused.mlp_from(self, buf, sky_c, sky_avg.reshape(-1), win.n_rays, num_samples, window=win).view(1, Hp, Wp, 64)
+            if one:
+                net_out = fused.field_render(self, *buf, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, num_samples,
+                                             window=win).view(1, Hp, Wp, 64)
+            else:
+                net_out = fused.mlp_from(self, buf, sky_c, sky_avg.reshape(-1), win.n_rays, num_samples, window=win).view(1, Hp, Wp, 64)
             if probe is not None:
                 e1.record(main)
                 probe.setdefault("mlp_kernel", []).append((e0, e1))

@@ -413,3 +413,38 @@ def test_mx_weight_image_decodes_to_the_weights(renderer):
                     err = np.abs(np.abs(val) - np.abs(ref)).max() / max(np.abs(ref).max(), 1e-30)
                     worst[term] = max(worst[term], float(err))
     assert worst[0] < 0.07 and worst[1] < 0.07, worst            # fp6 step in the top binade: 0.5 / 7.5 of the block maximum
+
+
+def test_single_kernel_field_equals_the_two_kernel_field(renderer):
+    """sdn_field_render (field_kernel: every pass places its samples and gathers its features itself, then runs the MLP on
+    them) against sdn_field_encode + sdn_field_mlp: the same device functions produce the features either way, so net_out,
+    the per-group pass counts and the stochastic-sampling variant must agree bit for bit -- whole ray set, cropped window,
+    both precision profiles."""
+    from scenedreamer_amd import fused
+    pose, vid, d2, rd, H0, W0 = _frame(renderer)
+    ori = torch.as_tensor(pose[0], dtype=torch.float32)
+    with torch.no_grad():
+        sky_c, sky_avg = fused.sky_fused(renderer, rd)
+        n = vid.shape[0]
+        torch.manual_seed(3)
+        u = torch.rand(n, 13, device="cuda")
+        win = fused.Window.crop(H0, W0, 11)
+        uw = u[:win.n_rays].contiguous()
+        try:
+            for ct in (6, 3):
+                renderer.set_precision(colour_terms=ct)
+                outs = {}
+                for one in (False, True):
+                    renderer.field_single_kernel = one
+                    pa = torch.zeros((n + 31) // 32, dtype=torch.uint8, device="cuda")
+                    a = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, 12, passes=pa)
+                    b = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, 12, window=win)
+                    c = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, 12, u=uw, window=win)
+                    outs[one] = (a, b, c, pa)
+                for x, y in zip(outs[False], outs[True]):
+                    assert x.shape == y.shape and torch.equal(x, y)
+                assert float(outs[True][0].std()) > 1e-2 and int(outs[True][3].sum()) > 0
+                assert not torch.equal(outs[True][1], outs[True][2])          # (the stochastic draw does change the result)
+        finally:
+            renderer.field_single_kernel = None
+            renderer.set_precision()

@@ -19,7 +19,8 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = {"field.hip": ["-fno-slp-vectorize"], "cnn.hip": []}
-KERNELS = ("mlp_kernelILi0ELi3", "mlp_kernelILi0ELi2", "mlp_kernelILi0ELi6", "sky_kernelILi0ELi0", "sky_kernelILi0ELi1", "conv_kernelILi9ELi0ELi3ELi16E", "conv_kernelILi9ELi0ELi3ELi27E", "conv_kernelILi9ELi0ELi3ELi255E",
+# (mlp_kernel<DBG, CT, FUSED>: ...Lb1E = field_kernel, the single-kernel field: no input prefetch, a[190:255] are ordinary registers)
+KERNELS = ("mlp_kernelILi0ELi3ELb0E", "mlp_kernelILi0ELi2ELb0E", "mlp_kernelILi0ELi6ELb0E", "mlp_kernelILi0ELi3ELb1E", "mlp_kernelILi0ELi6ELb1E", "sky_kernelILi0ELi0", "sky_kernelILi0ELi1", "conv_kernelILi9ELi0ELi3ELi16E", "conv_kernelILi9ELi0ELi3ELi27E", "conv_kernelILi9ELi0ELi3ELi255E",
            "conv_kernelILi9ELi0ELi1ELi0E", "conv_kernelILi9ELi0ELi1ELi16E", "conv_kernelILi9ELi0ELi1ELi27E", "conv_kernelILi9ELi0ELi1ELi255E",
            "conv_kernelILi1ELi0ELi3ELi16E", "conv_kernelILi1ELi0ELi3ELi255E")
 REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
@@ -198,7 +199,7 @@ def main():
                 body = list(enumerate(text[start:end], start + 1))
                 n, problems = check_kernel(k, body)
                 print(f"{src}:{k}: {n} LDS reads replayed, {len(problems)} hazard(s)")
-                if k.startswith("mlp_kernel"):
+                if k.startswith("mlp_kernel") and k.endswith("ELb0E"):
                     n2, p2, nf = check_prefetch_agprs(body)
                     print(f"{src}:{k}: {n2} instructions on the prefetch AGPRs a[190:255]: {nf} compiler-generated "
                           f"(spill space while the registers are dead), {len(p2)} violation(s)")
