@@ -210,6 +210,11 @@ def _reference_tiles(weights, scene, vox, pose, hw, ns, z, genc, picks, pad=30, 
     return t_frame, t_tiles, got
 
 
+def _single_kernel(R):
+    from scenedreamer_amd import fused
+    return fused.single_kernel(R) and fused.precision_profile(R)[0] != 2
+
+
 def fused_eps(R):
     from scenedreamer_amd import fused
     return fused.precision_profile(R)[1]
@@ -355,12 +360,25 @@ def main():
         # stream it went to (main stream: mlp_kernel; side stream: encode_kernel), work averaged over the same poses
         ms_of = lambda k: float(np.mean([a.elapsed_time(b) for a, b in probe[k]]))
         B, hit, ev = R.field_work(timed_poses, hw, args.samples, args.apron)
-        roof, roof_grid = R.roofline_records(
-            B, ms_of("encode_kernel"), ms_of("mlp_kernel"), hit, ev,
-            "encode_kernel (collapsed 3-D table: 4096 B/sample actually gathered)",
-            timing=f"HIP events around each of the {len(probe['mlp_kernel'])} launches of the timed region, on the launch stream "
-                   "(mlp_kernel: main; encode_kernel: side stream, where it shares the GPU with the previous frame's "
-                   "mlp_kernel / conv_kernel -- its stand-alone duration is `standalone_ms`)")
+        one_kernel = "encode_kernel" not in probe      # field_kernel: lookup + MLP in one launch, no separate encode launch
+        alone = None
+        if one_kernel or not args.profile:             # stand-alone launches of encode_kernel / mlp_kernel, outside the timed region
+            alone = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
+        if one_kernel:
+            roof, roof_grid = R.roofline_records(
+                B, alone[1]["avg_launch_ms"] * B / alone[1]["samples_per_launch"], ms_of("mlp_kernel"), hit, ev,
+                "the encode stage (collapsed 3-D table: 4096 B/sample actually gathered) -- in the timed region it runs INSIDE "
+                "field_kernel; timed here as encode_kernel (the same device functions) alone, outside the timed region",
+                timing=f"field_kernel: HIP events around each of the {len(probe['mlp_kernel'])} launches of the timed region on the "
+                       "main stream; grid sampler: 5 back-to-back stand-alone launches of encode_kernel on the whole padded frame, "
+                       "scaled to the samples of a timed launch", field_kernel=True)
+        else:
+            roof, roof_grid = R.roofline_records(
+                B, ms_of("encode_kernel"), ms_of("mlp_kernel"), hit, ev,
+                "encode_kernel (collapsed 3-D table: 4096 B/sample actually gathered)",
+                timing=f"HIP events around each of the {len(probe['mlp_kernel'])} launches of the timed region, on the launch stream "
+                       "(mlp_kernel: main; encode_kernel: side stream, where it shares the GPU with the previous frame's "
+                       "mlp_kernel / conv_kernel -- its stand-alone duration is `standalone_ms`)")
         # render CNN (5 015 040 FLOP per pixel of the evaluated frame): its seven launches share the GPU with the
         # next frame's sky MLP / sample encode on the side stream in the timed region; `stage_ms.cnn` is the same CNN alone
         px = (hw[0] + 8) * (hw[1] + 8) if args.apron == "minimal" else (hw[0] + 30) * (hw[1] + 30)
@@ -374,12 +392,12 @@ def main():
                     "alone_ms": stage_ms.get("cnn"),
                     "frac_alone": (px * 5015040 / (stage_ms["cnn"] * 1e-3) / 1e12 / 2500.0) if stage_ms.get("cnn") else None,
                     "timing": "HIP events around the CNN of every timed frame on the main stream"}
-        if not args.profile:
-            alone = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
+        if alone is not None:
             roof["standalone_ms"], roof_grid["standalone_ms"] = alone[0]["avg_launch_ms"], alone[1]["avg_launch_ms"]
             roof["standalone_note"] = roof_grid["standalone_note"] = (
-                "standalone_ms: 5 back-to-back launches of the kernel alone on the whole padded frame "
-                f"({alone[0]['samples_per_launch']} samples), outside the timed region")
+                "standalone_ms: 5 back-to-back launches of "
+                + ("mlp_kernel (the MLP stage alone, features pre-encoded) / encode_kernel" if one_kernel else "the kernel")
+                + f" alone on the whole padded frame ({alone[0]['samples_per_launch']} samples), outside the timed region")
     else:
         roof, roof_grid = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
 
@@ -398,6 +416,8 @@ def main():
                                       else "1 frame per rank per step"),
                        "baseline_config": args.config or (2 if (hw, args.samples, args.scene_size) == ((540, 960), 24, 2048) else None),
                        "path": mode, "apron": "reference" if tile_parallel else args.apron,
+                       "field": ("one kernel (field_kernel: sample placement + hash-grid lookup + MLP + compositing)"
+                                 if mode == "fused" and _single_kernel(R) else "encode_kernel -> HBM -> mlp_kernel") if mode == "fused" else None,
                        "ray_casting_overlap": not (args.no_overlap or mode != "fused"),
                        "scene_volume": ("uint8 palette indices" if getattr(scene, "voxel_u8", None) is not None else "int32 block ids"),
                        "padded_rays": (hw[0] + 30) * (hw[1] + 30),

@@ -354,9 +354,11 @@ class Renderer:
         k = max(1, len(poses))
         return B / k, hits / k, dict(group_hit_fraction=groups / k, evaluated_samples=evald / k, passes_skipped_by_termination=0)
 
-    def roofline_records(self, B, ms_enc, ms_mlp, hit, ev, kernel, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0, timing=""):
+    def roofline_records(self, B, ms_enc, ms_mlp, hit, ev, kernel, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0, timing="",
+                         field_kernel=False):
         """(field-MLP record, grid-sampler record) from per-launch work (B samples, hit fraction, evaluated samples in
-        `ev`) and average launch durations."""
+        `ev`) and average launch durations.  field_kernel: ms_mlp is the duration of the single-kernel field (its launches
+        contain the encode stage as well: the MLP's algorithmic FLOPs are divided by the WHOLE launch time)."""
         from . import fused
         traffic, traffic_src = _profiled_traffic()
         ct, eps = fused.precision_profile(self)
@@ -390,7 +392,9 @@ class Renderer:
         # issue time of one K = 16 f16 MFMA)
         issued = (2208 - (256 if ct == 2 else 384 if ct == 6 else 0)) / 736.0
         colour = {2: "2-term", 3: "3-term", 6: "f16 + MX-fp6 corrections"}[ct]
-        mlp = {"bound": "mfma", "kernel": f"mlp_kernel (f16 MFMA, 3-term split, colour layers {colour}, f32 accumulate)",
+        name = ("field_kernel = mlp_kernel<FUSED>: sample placement + collapsed hash-grid lookup + MLP + compositing in ONE launch"
+                if field_kernel else "mlp_kernel")
+        mlp = {"bound": "mfma", "kernel": f"{name} (f16 MFMA, 3-term split, colour layers {colour}, f32 accumulate)",
                "achieved": ach_m, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach_m / mfma_peak_tflops,
                "traffic": traffic.get("mlp_kernel"), "traffic_source": traffic_src,
                "samples_per_launch": B, "samples_evaluated": n_eval, "algorithmic_flop_per_sample": 754176,
@@ -399,7 +403,10 @@ class Renderer:
                "issued_over_algorithmic": issued, "issued_frac_of_peak": ach_m * issued / mfma_peak_tflops,
                "timing": timing,
                "achieved_counting_skipped_samples": B * 754176 / (ms_mlp * 1e-3) / 1e12,
-               "note": "achieved = samples evaluated x 754 176 FLOP / launch time (skipped sky groups are not counted as "
+               "note": ("the launch ALSO contains the encode stage of its samples (sample placement + 8-corner gathers of 16 levels, "
+                        "the work of the former encode_kernel): its time is in the denominator, its bytes are not in the numerator; "
+                        if field_kernel else "") +
+                       "achieved = samples evaluated x 754 176 FLOP / launch time (skipped sky groups are not counted as "
                        "work); the kernel issues `issued_over_algorithmic` MFMA slots per algorithmic product (hi*hi + "
                        "lo*hi + hi*lo: plain f16 misses the 1e-3 bound 17x; in the colour layers the two corrections run as "
                        "block-scaled fp6 at 4x the rate); traffic = HBM bytes per launch from the "
