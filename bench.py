@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--volume", default="compact", choices=["compact", "int32"],
                     help="scene volume the rays walk: uint8 palette indices + int32 palette (scene.py, 4x smaller, what the "
                          "ranks receive; voxel ids come out identical) or the reference's int32 block ids")
+    ap.add_argument("--field", default=None, choices=["one-kernel", "two-kernel"],
+                    help="fused path: sample placement + hash-grid lookup + MLP + compositing as ONE kernel (default) or as "
+                         "encode_kernel -> feature buffer in HBM -> mlp_kernel (the round-1/2 form, kept for A/B runs)")
     ap.add_argument("--backend", default=os.environ.get("SDN_DIST_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="torch.distributed backend for --gpus N > 1: nccl (= RCCL over xGMI, one GPU per rank: the production path) "
                          "or gloo (collectives staged through host memory by scenedreamer_amd.dist; lets N ranks share one GPU, "
@@ -265,6 +268,8 @@ def main():
         scene = scene_mod.to_compact(scene)
     R = Renderer(weights, scene, dev)
     R.set_style(style)
+    if args.field is not None:
+        R.field_single_kernel = args.field == "one-kernel"
     maxstep = args.cam_maxstep
     poses = camera.eval_camera_poses(scene, maxstep=maxstep)
     # global frame f uses pose (stride * f) % maxstep (default: every 2nd pose of the 40-pose orbit)
@@ -392,6 +397,10 @@ def main():
                     "alone_ms": stage_ms.get("cnn"),
                     "frac_alone": (px * 5015040 / (stage_ms["cnn"] * 1e-3) / 1e12 / 2500.0) if stage_ms.get("cnn") else None,
                     "timing": "HIP events around the CNN of every timed frame on the main stream"}
+        if one_kernel:   # the MLP stage by itself (mlp_kernel on pre-encoded features: the same layers without the encode stage)
+            roof["mlp_stage_alone"] = {"kernel": "mlp_kernel (stand-alone launches on pre-encoded features, outside the timed region)",
+                                       "avg_launch_ms": alone[0]["avg_launch_ms"], "achieved": alone[0]["achieved"],
+                                       "frac": alone[0]["frac"], "samples_evaluated": alone[0]["samples_evaluated"]}
         if alone is not None:
             roof["standalone_ms"], roof_grid["standalone_ms"] = alone[0]["avg_launch_ms"], alone[1]["avg_launch_ms"]
             roof["standalone_note"] = roof_grid["standalone_note"] = (

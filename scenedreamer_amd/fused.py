@@ -208,7 +208,7 @@ def single_kernel(R):
     return bool(v)
 
 
-SINGLE_KERNEL_DEFAULT = "0"
+SINGLE_KERNEL_DEFAULT = "1"   # same frame time as the two-kernel sequence (A/B), without its 10.8 GB/frame of HBM hand-off
 
 
 def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None, window=None, division="reciprocal",

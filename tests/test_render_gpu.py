@@ -108,9 +108,13 @@ def test_ray_chunking_is_bit_identical(renderer, scene256, monkeypatch):
     from scenedreamer_amd import camera, fused
     pose = camera.eval_camera_poses(scene256, maxstep=8)[3]
     a = renderer.render_frame(pose, (64, 72), 12, mode="fused")
-    monkeypatch.setattr(fused, "FEATURE_BUFFER_BYTES", 12 * 512 * 1000)      # ~1000 rays per chunk -> 6 chunks, ragged last
-    b = renderer.render_frame(pose, (64, 72), 12, mode="fused")
-    assert torch.equal(a, b)
+    try:
+        renderer.field_single_kernel = False      # the chunked form belongs to the two-kernel field (its feature buffer)
+        monkeypatch.setattr(fused, "FEATURE_BUFFER_BYTES", 12 * 512 * 1000)      # ~1000 rays per chunk -> 6 chunks, ragged last
+        b = renderer.render_frame(pose, (64, 72), 12, mode="fused")
+    finally:
+        renderer.field_single_kernel = None
+    assert torch.equal(a, b)        # and both equal the single-kernel field (the default) that rendered `a`
 
 
 @pytest.mark.parametrize("terms3x3,bound", [(3, 2e-4), (1, 8e-4)])
