@@ -521,17 +521,24 @@ __device__ __forceinline__ void enc_level_load(const LevelAddr &a, float4 (&va)[
 }
 
 __device__ __forceinline__ void enc_level_blend(const LevelAddr &a, const float4 (&va)[8], const float4 (&vb)[8], float (&res)[8]) {
-#pragma unroll
-    for (int c = 0; c < 8; c++) res[c] = 0.f;
+    // res[ch] = fma(w_c, row_c[ch], res[ch]) over the corners in order, two channels per v_pk_fma_f32 (the same fused
+    // multiply-add per channel as the scalar form -- bit-identical -- in half the issue slots: this stage runs with one wave
+    // per SIMD inside field_kernel, where every instruction is ~4 cycles of an idle matrix pipe)
+    float2v r01 = {0.f, 0.f}, r23 = {0.f, 0.f}, r45 = {0.f, 0.f}, r67 = {0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         float w = 1.f;  // same multiply order as gridencoder.cu:152-160
         w *= (c & 1) ? a.f0 : 1.f - a.f0;
         w *= (c & 2) ? a.f1 : 1.f - a.f1;
         w *= (c & 4) ? a.f2 : 1.f - a.f2;
-        res[0] += w * va[c].x; res[1] += w * va[c].y; res[2] += w * va[c].z; res[3] += w * va[c].w;
-        res[4] += w * vb[c].x; res[5] += w * vb[c].y; res[6] += w * vb[c].z; res[7] += w * vb[c].w;
+        const float2v w2 = {w, w};
+        r01 = __builtin_elementwise_fma(w2, float2v{va[c].x, va[c].y}, r01);
+        r23 = __builtin_elementwise_fma(w2, float2v{va[c].z, va[c].w}, r23);
+        r45 = __builtin_elementwise_fma(w2, float2v{vb[c].x, vb[c].y}, r45);
+        r67 = __builtin_elementwise_fma(w2, float2v{vb[c].z, vb[c].w}, r67);
     }
+    res[0] = r01[0]; res[1] = r01[1]; res[2] = r23[0]; res[3] = r23[1];
+    res[4] = r45[0]; res[5] = r45[1]; res[6] = r67[0]; res[7] = r67[1];
 }
 
 // one level at a time (encode_kernel: its other waves hide the round trip); no loads at all for lanes without a sample
@@ -547,8 +554,12 @@ __device__ __forceinline__ void enc_level(const EncParams &p, const EncSample &e
     }
 }
 
-// NB levels 2 * (S0 + t) + h, t = 0 .. NB-1, with all their gathers issued before the first blend (branch-free: lanes without
-// a sample gather row 0 and get zeros by selection).  The arithmetic of a lane that has a sample is enc_level's, bit for bit.
+// field_kernel's form: NB levels 2 * (S0 + t) + h, t = 0 .. NB-1, with all their gathers issued before the first blend, and
+// branch-free: lanes without a sample gather row 0 and get zeros by selection.  The arithmetic of a lane that has a sample is
+// enc_level's, bit for bit.  (NB = 4: 64 x 16 B in flight per lane, 2 round trips per pass.  A 2-deep software pipeline of
+// 2-level batches was tried: its register pressure made hipcc spill, and a scratch reload is a vector-memory operation -- the
+// wait for it drains every gather issued before it.  The stage moves 512 KiB per CU and pass from L2: ~4 us at the L2's
+// 135 GB/s per CU whatever the schedule.)
 template <int NB>
 __device__ __forceinline__ void enc_levels(const EncParams &p, const EncSample &e, int s0, int h, bool use_feat, float (&res)[NB][8]) {
     const bool ok = !e.oob && e.valid && use_feat;
