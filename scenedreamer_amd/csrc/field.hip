@@ -483,8 +483,10 @@ __device__ __forceinline__ EncSample enc_place(const EncParams &p, const RayBoxe
     e.dist = e.valid ? pl.dist * p.dists_scale : 0.f;
     int id = rb.id[0];
 #pragma unroll
-    for (int k = 1; k < MAXM; k++)
-        if (k == pl.idx) id = rb.id[k];
+    for (int k = 1; k < MAXM; k++) {
+        id = k == pl.idx ? rb.id[k] : id;
+        asm("" : "+v"(id));     // a select chain, not rb.id[pl.idx]: hipcc otherwise turns it into a dynamically indexed load
+    }                           // and moves the ray's boxes to scratch memory (8 stores + 1 load per sample)
     e.label = p.lut[id & 1023];
     return e;
 }
@@ -494,7 +496,9 @@ __device__ __forceinline__ EncSample enc_place(const EncParams &p, const RayBoxe
 // a level's round trip behind): where the rows are, the rows, the blend in the reference's multiply order.
 struct LevelAddr {
     float f0, f1, f2;       // fractional position inside the cell
-    const float *row[8];    // corner c: bit d of c = +1 on dimension d
+    uint32_t off[8];        // byte offset of corner c's row from table3 (corner c: bit d of c = +1 on dimension d); 32 bits: the
+                            // 16 x T x 32-byte table is far below 4 GiB, and a uniform base + 32-bit lane offset is the saddr form
+                            // of global_load -- half the address registers of 64-bit pointers (64 instead of 128 per 4 levels)
 };
 
 __device__ __forceinline__ void enc_level_addr(const EncParams &p, const EncSample &e, int level, bool ok, LevelAddr &a) {
@@ -504,19 +508,20 @@ __device__ __forceinline__ void enc_level_addr(const EncParams &p, const EncSamp
     a.f0 = f0 - g0; a.f1 = f1 - g1; a.f2 = f2 - g2;
     const uint32_t a0 = (uint32_t)g0, a1 = (uint32_t)g1 * 2654435761u, a2 = (uint32_t)g2 * 805459861u;
     const uint32_t b0 = a0 + 1u, b1 = a1 + 2654435761u, b2 = a2 + 805459861u;
-    const float *tb = p.table3 + (size_t)level * ((size_t)p.tmask + 1) * 8;
+    const uint32_t tb = (uint32_t)level * (p.tmask + 1u);     // first row of the level
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const uint32_t hsh = ((c & 1) ? b0 : a0) ^ ((c & 2) ? b1 : a1) ^ ((c & 4) ? b2 : a2);
-        a.row[c] = tb + (size_t)(ok ? (hsh & p.tmask) : 0u) * 8;     // (lanes without a sample read row 0 and discard it)
+        a.off[c] = (tb + (ok ? (hsh & p.tmask) : 0u)) * 32u;      // (lanes without a sample read row 0 and discard it)
     }
 }
 
-__device__ __forceinline__ void enc_level_load(const LevelAddr &a, float4 (&va)[8], float4 (&vb)[8]) {
+__device__ __forceinline__ void enc_level_load(const EncParams &p, const LevelAddr &a, float4 (&va)[8], float4 (&vb)[8]) {
+    const char *base = reinterpret_cast<const char *>(p.table3);
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        va[c] = *reinterpret_cast<const float4 *>(a.row[c]);
-        vb[c] = *reinterpret_cast<const float4 *>(a.row[c] + 4);
+        va[c] = *reinterpret_cast<const float4 *>(base + a.off[c]);
+        vb[c] = *reinterpret_cast<const float4 *>(base + a.off[c] + 16);
     }
 }
 
@@ -549,7 +554,7 @@ __device__ __forceinline__ void enc_level(const EncParams &p, const EncSample &e
         LevelAddr a;
         float4 va[8], vb[8];
         enc_level_addr(p, e, level, true, a);
-        enc_level_load(a, va, vb);
+        enc_level_load(p, a, va, vb);
         enc_level_blend(a, va, vb, res);
     }
 }
@@ -568,7 +573,7 @@ __device__ __forceinline__ void enc_levels(const EncParams &p, const EncSample &
 #pragma unroll
     for (int t = 0; t < NB; t++) enc_level_addr(p, e, 2 * (s0 + t) + h, ok, a[t]);
 #pragma unroll
-    for (int t = 0; t < NB; t++) enc_level_load(a[t], va[t], vb[t]);
+    for (int t = 0; t < NB; t++) enc_level_load(p, a[t], va[t], vb[t]);
 #pragma unroll
     for (int t = 0; t < NB; t++) {
         enc_level_blend(a[t], va[t], vb[t], res[t]);
@@ -578,7 +583,7 @@ __device__ __forceinline__ void enc_levels(const EncParams &p, const EncSample &
 }
 
 #ifndef SDN_ENC_OCC
-#define SDN_ENC_OCC 1
+#define SDN_ENC_OCC 3   // 3 waves per SIMD = up to 168 VGPRs: no spills (with 1, hipcc aims at 4 waves and spills 100 B; 4 and 5 measured slower)
 #endif
 __global__ __launch_bounds__(256, SDN_ENC_OCC) void encode_kernel(const EncParams p) {
     const int lane = threadIdx.x & 63;
