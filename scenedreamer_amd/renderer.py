@@ -598,10 +598,15 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
 
     # (Issuing the next front half only behind this frame's MLP was measured: mlp_kernel 16.2 -> 15.8 ms without the ray caster
     # beside its start, but the frame 22.4 -> 22.8 ms, because the ray caster then lands in the CNN phase too.)
+    # where the next frame's front half (ray casting + sky MLP [+ encode]) is released: "early" = as soon as the previous
+    # frame's CNN has been enqueued, i.e. beside this frame's field kernel; "late" = behind this frame's field kernel, i.e. beside
+    # its CNN.  (SDN_FRONT=late|early; measured in DESIGN.md section 6.)
+    late = deep and os.environ.get("SDN_FRONT", FRONT_DEFAULT) == "late"
     nxt = front(poses[0], 0)
     for i, pose in enumerate(poses):
         cur, done = nxt
-        nxt = front(poses[i + 1], (i + 1) & 1) if i + 1 < len(poses) else None
+        if not late:
+            nxt = front(poses[i + 1], (i + 1) & 1) if i + 1 < len(poses) else None
         main.wait_event(done)
         if not deep:
             yield self.render_frame(pose, resolution_hw, num_samples, mode=mode, apron=apron, _precast=cur, **kw)
@@ -619,6 +624,8 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
             if probe is not None:
                 e1.record(main)
                 probe.setdefault("mlp_kernel", []).append((e0, e1))
+            if late:
+                nxt = front(poses[i + 1], (i + 1) & 1) if i + 1 < len(poses) else None
             cnn = self.mfma_cnn(net_out)         # (first frame of a style: calibrates the 3x3 precision, see mfma_cnn)
             if probe is not None:
                 c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -633,6 +640,7 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
 
 Renderer.render_frames = _render_frames
 
+FRONT_DEFAULT = "early"
 CNN_AUTO_BOUND = 5e-4   # mfma_cnn: largest image difference (max abs) at which the 1-term 3x3 convolutions are accepted
 CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (conv2a, conv2b, conv3a, conv3b)
 
