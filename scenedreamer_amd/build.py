@@ -43,7 +43,7 @@ def _hipcc():
 
 def _digest():
     h = hashlib.sha256()
-    h.update(os.environ.get("SDN_FIELD_CFLAGS", "").encode())
+    h.update((os.environ.get("SDN_FIELD_CFLAGS", "") + ("|ablation" if os.environ.get("SDN_MLP_ABLATION") else "")).encode())
     names = sorted(n for n in os.listdir(CSRC) if n.endswith((".hip", ".h"))) + ["../../include/sdnative.h", "../build.py"]
     for n in names:
         p = os.path.join(CSRC, n)

@@ -145,6 +145,22 @@ struct MlpParams {
     EncParams enc;             // FUSED (field_kernel): the encode stage's inputs; feat / dist / label / rayflag are unused then
 };
 
+// Exchanges inside a quad of lanes (the 4 samples of a ray in a pass) as DPP operands of the consuming VALU instruction:
+// __shfl_* compiles to ds_bpermute_b32, an LDS round trip per exchange (64 of them in the volume-rendering epilogue of a pass).
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int quad_dpp(int v) {
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+constexpr int QUAD_XOR1 = 0xB1;    // quad_perm [1,0,3,2]: lane ^ 1
+constexpr int QUAD_XOR2 = 0x4E;    // quad_perm [2,3,0,1]: lane ^ 2
+constexpr int QUAD_UP1 = 0x90;     // quad_perm [0,0,1,2]: lane - 1 (lane 0 of the quad reads itself)
+constexpr int QUAD_UP2 = 0x44;     // quad_perm [0,1,0,1]: lane - 2 (lanes 0, 1 read themselves)
+constexpr int QUAD_LAST = 0xFF;    // quad_perm [3,3,3,3]: the quad's last lane
+
 // =====================================================================================================
 // collapse
 // =====================================================================================================
@@ -636,8 +652,8 @@ __global__ __launch_bounds__(256, SDN_ENC_OCC) void encode_kernel(const EncParam
         }
     }
     // per-ray flags: any over the ray's 4 lanes
-    gnd = __shfl_xor((int)gnd, 1) | (int)gnd;
-    gnd = __shfl_xor((int)gnd, 2) | (int)gnd;
+    gnd = quad_dpp<QUAD_XOR1>((int)gnd) | (int)gnd;
+    gnd = quad_dpp<QUAD_XOR2>((int)gnd) | (int)gnd;
     if (h == 0 && (j & 3) == 0 && ray_ok) {
         const bool sky_only = rb.id[0] == 0;             // scenedreamer.py:337
         int last = rb.id[0];
@@ -728,7 +744,8 @@ constexpr int LDS_FLAGS = LDS_CONST + ((C_TOTAL * 4 + 255) / 256) * 256;
 constexpr int LDS_ENC_SCALES = LDS_FLAGS + 64;              // f32 [16]   per-level scales
 constexpr int LDS_ENC_LIN = LDS_ENC_SCALES + NLEV * 4;      // f32 [MAX_LIN] stratified positions
 constexpr int LDS_ENC_LUT = LDS_ENC_LIN + MAX_LIN * 4;      // u8 [1024]  block id -> reduced label
-constexpr int LDS_TOTAL = LDS_ENC_LUT + 1024;
+constexpr int LDS_TIMERS = LDS_ENC_LUT + 1024;            // u32 [16]  DBG & 512: cycles per segment of a pass (timing experiments)
+constexpr int LDS_TOTAL = LDS_TIMERS + 64;
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const char glb_char;
@@ -1027,7 +1044,8 @@ constexpr int RING_DEPTH = 3;   // register ring of fragment units: 2 units (384
 
 struct LayerState {
     half8 ring[RING_DEPTH][4];
-    ActIn in[2];                // activation inputs of unit U in in[U & 1], fetched during unit U-1
+    ActIn in[2];                // activation inputs of the half fragment that STARTS in unit U, fetched during unit U-1 (ActPlan::SLOT)
+    ActRegs g;                  // a half fragment in flight across two units (ActPlan::PHASE 1 -> 2)
     int pos_cur, pos_nxt;
 };
 
@@ -1038,42 +1056,68 @@ __device__ __forceinline__ void lds_frag(const Ring &r, int pos, half8 &dst) {
 }
 
 // which activation work is hidden in unit U of a layer8
-template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
+//
+// What one in-order wave per SIMD can hide behind a unit's MFMAs is bounded by ISSUE time, not by the matrix pipe
+// (tools/unit_cost_ubench.hip): a unit of 6 MFMAs with its 5 LDS reads hides ~18 VALU instructions; the ~36 of a whole half
+// fragment make it 267 cycles instead of 201.  So a 16-k-step layer whose activation work has 60 units to go to spreads it
+// (SPREAD): a half fragment takes TWO units -- stages 0..2 in one (PHASE 1), 3..5 in the next (PHASE 2), its registers kept
+// in LayerState::g -- except the two that the deadlines leave one unit for (PHASE 0, all six stages as before):
+//   pending (previous layer's lower half -> fragments 8..15; fragment 8+k is first needed at unit 16+2k):
+//       half fragment j = 0, 1 in units 0, 1;  j >= 2 in units 2j-2, 2j-1  (j = 15: units 28, 29 < 30)
+//   own (this layer's upper half -> fragments 0..7; fragment T is free from unit 34+2T on):
+//       half fragment j <= 13 in units 34+2j, 35+2j (fragment T from unit 34+4T);  j = 14, 15 in units 62, 63
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U, bool SPREAD = false>
 struct ActPlan {
     static constexpr bool IN_RANGE = U >= 0 && U < NS * 4;
     static constexpr int HALF = U / (2 * NS), REM = U % (2 * NS), S = REM >> 1;
     // the previous layer's lower half (fragments 8..15, half a fragment per unit over units 0..15: fragment 8+k
     // is first needed at unit 16+2k), or this layer's upper half (fragments 0..NS/2-1) during the last NS/2 k-steps
     // of the lower half
-    static constexpr bool PEND = IN_RANGE && HAS_PEND && U < 16 && !(DBG & 4);
+    static constexpr bool PEND = IN_RANGE && HAS_PEND && U < (SPREAD ? 30 : 16) && !(DBG & 4);
     // own: fragment T may be overwritten once k-step T has been consumed by both row blocks of this half, i.e. from
     // k-step T+1 on.  NS == 16: fragments 0..7 during k-steps 8..15; NS < 16 (first layers): fragments 0..NS-2 during
     // k-steps 1..NS-1 (the last upper-half fragments are activated after the layer, un-hidden)
     static constexpr int S0 = NS == 16 ? 8 : 1;
-    static constexpr bool OWN = IN_RANGE && HALF == 1 && S >= S0 && !(DBG & 4);
+    static constexpr bool OWN = IN_RANGE && (SPREAD ? U >= 34 : (HALF == 1 && S >= S0)) && !(DBG & 4);
     static constexpr int M = U - 2 * NS - 2 * S0;
-    static constexpr int T = PEND ? 8 + U / 2 : (OWN ? M / 2 : 0);
-    static constexpr int HS = PEND ? U % 2 : (OWN ? M % 2 : 0);
+    // half fragment index within its group and the part of it done in this unit
+    static constexpr int J = !SPREAD ? (PEND ? U : (OWN ? M : 0))
+                             : PEND ? (U < 2 ? U : 2 + (U - 2) / 2)
+                             : OWN  ? (U >= 62 ? 14 + (U - 62) : (U - 34) / 2) : 0;
+    static constexpr int PHASE = !SPREAD ? 0 : PEND ? (U < 2 ? 0 : 1 + (U - 2) % 2) : OWN ? (U >= 62 ? 0 : 1 + (U - 34) % 2) : 0;
+    static constexpr int T = PEND ? 8 + J / 2 : (OWN ? J / 2 : 0);
+    static constexpr int HS = J % 2;
     static constexpr bool SIG = PEND ? SIG_PEND : SIG_OWN;
     static constexpr bool ACT = PEND || OWN;
+    static constexpr bool STARTS = ACT && PHASE != 2;       // its inputs are fetched one unit earlier ...
+    static constexpr int SLOT = SPREAD ? J % 2 : U % 2;     // ... into this ActIn (consecutive half fragments alternate)
+    // activation stage (0..5, or -1) behind MFMA K (0..5) of this unit; a half-rate unit uses the two gaps without
+    // fragment reads and one of the others
+    static constexpr int stage(int K) {
+        return !ACT ? -1 : PHASE == 0 ? K : (K == 2 ? 0 : K == 4 ? 1 : K == 5 ? 2 : -4) + (PHASE == 2 ? 3 : 0);
+    }
 };
 
-template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U>
+template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U, bool SPREAD = false>
 __device__ __forceinline__ void layer8_fetch(const float *bias, const float *bias_pend, const float *wsig, int h, LayerState &st) {
-    using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U>;
-    if constexpr (P::ACT) act_fetch<P::T, P::HS, P::SIG>(P::PEND ? bias_pend : bias, wsig, h, st.in[U & 1]);
+    using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U, SPREAD>;
+    if constexpr (P::STARTS) act_fetch<P::T, P::HS, P::SIG>(P::PEND ? bias_pend : bias, wsig, h, st.in[P::SLOT]);
 }
 
 // TERMS = 3: Whi.Xhi + Wlo.Xhi + Whi.Xlo (6 MFMAs per unit);  TERMS = 2: the Whi.Xlo products are dropped (4 MFMAs per
 // unit; the colour layers fc_5 / fc_6, whose error is not amplified by the density head -- DESIGN.md).
 // LO_PEND / LO_OWN: whether the fragments activated in this layer (previous layer's lower half / this layer's upper
 // half) need their lo part, i.e. whether their CONSUMER is a 3-term layer.
+// the layers whose activation work is spread at half rate (ActPlan): 16 k-steps, 6 MFMAs per unit, pending work
+constexpr bool layer8_spread(int NS, bool HAS_PEND, int TERMS) { return NS == 16 && HAS_PEND && TERMS == 3; }
+
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS, bool LO_PEND, bool LO_OWN, int U>
 __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
                                             f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
                                             int h, float &part) {
     constexpr int UNITS = NS * 4, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
-    using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U>;
+    constexpr bool SPREAD = layer8_spread(NS, HAS_PEND, TERMS) && !(DBG & 16);
+    using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U, SPREAD>;
     if constexpr (U % UPS == 0 && U != 0) {
         st.pos_cur = ring_acquire<DBG>(lds, r);
         st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
@@ -1085,18 +1129,19 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     constexpr int T = P::T, HS = P::HS;
     constexpr bool SIG = P::SIG, ACT = P::ACT;
     constexpr bool LO = P::PEND ? LO_PEND : LO_OWN;
-    ActRegs g;
+    ActRegs g_unit;
+    ActRegs &g = SPREAD ? st.g : g_unit;
     half8(&a)[4] = st.ring[U % RD];
     half8(&nx)[4] = st.ring[UN % RD];
-    const ActIn &in = st.in[U & 1];
+    const ActIn &in = st.in[P::SLOT];
     // this unit's fragments (issued during unit U-2) and activation inputs (issued at the start of unit U-1) have
     // landed once only unit U-1's 4 fragment reads are outstanding
     constexpr bool PF_PREV = U == 0 || ((U - 1 + RD - 1) < UNITS && !(DBG & 8));
     lds_wait<PF_PREV ? 4 : 0>();
-    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
+    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1, SPREAD>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
     if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
-    if constexpr (ACT) act_stage<T, HS, SIG, K, LO>(acc, in, bh, bl, part, g); \
+    if constexpr (P::stage(K) >= 0) act_stage<T, HS, SIG, P::stage(K) < 0 ? 0 : P::stage(K), LO>(acc, in, bh, bl, part, g); \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DBG & 16) {
@@ -1147,7 +1192,7 @@ __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half
     LayerState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
-    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, 0>(bias, bias_pend, wsig, h, st);
+    layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, 0, layer8_spread(NS, HAS_PEND, TERMS) && !(DBG & 16)>(bias, bias_pend, wsig, h, st);
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
     layer8_units<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh,
@@ -1214,6 +1259,8 @@ __device__ __forceinline__ f32x16 mfma_mx(const half8 &a_lo, const half8 &a_hi, 
     // tools/check_lds_hazards.py reports exactly this)
     asm volatile("" ::"v"(a_hi));
     const u32x4v w0 = __builtin_bit_cast(u32x4v, a_lo), w1 = __builtin_bit_cast(u32x4v, a_hi);
+    // (a_hi's two code dwords are copied behind a_lo by two v_mov in front of every fp6 MFMA: the 6-register operand cannot
+    // overlap a 4-register fragment partially, whatever the vector is built from -- tried)
     const i32x8v A = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], 0, 0};
     const i32x8v B = {(int)b[0], (int)b[1], (int)b[2], (int)b[3], (int)b[4], (int)b[5], 0, 0};
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 2, 2, 0, (int)w1[2], OPB, sb);
@@ -1262,13 +1309,14 @@ __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st,
                                              int h, float &part) {
     constexpr int NS = 16, UNITS = 64, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
     constexpr bool MXL = KIND != 0;
-    using P = ActPlan<DBG, NS, true, SIG_PEND, SIG_OWN, U>;
+    constexpr bool SPREAD = !MXL;   // MX units (4 or 2 MFMAs) are issue-bound wherever the activation work goes
+    using P = ActPlan<DBG, NS, true, SIG_PEND, SIG_OWN, U, SPREAD>;
     if constexpr (U % UPS == 0 && U != 0) {
         st.pos_cur = ring_acquire<DBG>(lds, r);
         st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
     }
     constexpr int UN = U + RD - 1;
-    constexpr bool PF = UN < UNITS;
+    constexpr bool PF = UN < UNITS && !(DBG & 8);
     const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
     constexpr int T = P::T, HS = P::HS;
     constexpr bool SIG = P::SIG, ACT = P::ACT;
@@ -1276,17 +1324,18 @@ __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st,
     constexpr bool MXT = P::PEND ? MXL : KIND != 2;
     // K blocks completed by the previous unit: converted in this unit's first gap
     constexpr int CONV = (MXL && U == 0) ? 1 : (MXL && U == 8) ? 2 : (MXL && U == 16) ? 3 : (KIND != 2 && U == 56) ? 0 : -1;
-    ActRegs g;
+    ActRegs g_unit;
+    ActRegs &g = SPREAD ? st.g : g_unit;
     half8(&a)[4] = st.ring[U % RD];
     half8(&nx)[4] = st.ring[UN % RD];
-    const ActIn &in = st.in[U & 1];
-    constexpr bool PF_PREV = U == 0 || (U - 1 + RD - 1) < UNITS;
+    const ActIn &in = st.in[P::SLOT];
+    constexpr bool PF_PREV = U == 0 || ((U - 1 + RD - 1) < UNITS && !(DBG & 8));
     lds_wait<PF_PREV ? 4 : 0>();
-    layer8_fetch<DBG, NS, true, SIG_PEND, SIG_OWN, U + 1>(bias, bias_pend, wsig, h, st);
+    layer8_fetch<DBG, NS, true, SIG_PEND, SIG_OWN, U + 1, SPREAD>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
-    if constexpr (U % UPS < PIECES / 4 && K < 4) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
+    if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
     if constexpr (CONV >= 0 && K == 0) mx_convert<CONV < 0 ? 0 : CONV>(bh, bl, mx); \
-    if constexpr (ACT) act_stage_x<T, HS, SIG, K, MXT>(acc, in, bh, bl, mx, part, g); \
+    if constexpr (P::stage(K) >= 0) act_stage_x<T, HS, SIG, P::stage(K) < 0 ? 0 : P::stage(K), MXT>(acc, in, bh, bl, mx, part, g); \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!MXL) {
@@ -1349,7 +1398,7 @@ __device__ __forceinline__ void layer8x(char *lds, Ring &r, half8 (&bh)[16], hal
     LayerState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
-    layer8_fetch<DBG, 16, true, SIG_PEND, SIG_OWN, 0>(bias, bias_pend, wsig, h, st);
+    layer8_fetch<DBG, 16, true, SIG_PEND, SIG_OWN, 0, KIND == 0>(bias, bias_pend, wsig, h, st);
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
     layer8x_units<DBG, KIND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, 64>{}, lds, r, st, bh, bl, mx, acc, bias, bias_pend,
@@ -1357,19 +1406,30 @@ __device__ __forceinline__ void layer8x(char *lds, Ring &r, half8 (&bh)[16], hal
 }
 
 // Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of the last hidden layer is
-// activated behind its first 8 k-steps (one whole fragment = two half fragments per unit).
+// activated behind its first 15 k-steps (OutPlan).
 struct OutState {
     half8 ring[RING_DEPTH][4];
     ActIn in[2][2];
     int pos_cur, pos_nxt;
 };
 
+// which half fragment(s) of the last hidden layer's lower half unit U of the output layer activates: fragment 8+k is
+// consumed by unit 8+k, so half fragment j (fragment 8 + j/2) has to be finished in a unit < 8 + j/2.  Unit 0 takes
+// half fragments 0 and 1, unit u = 1..14 takes half fragment u+1 (deadline 8 + (u+1)/2 > u), unit 15 none: the
+// activation VALU work is spread over 15 units instead of packed two-deep into the first 8.
+template <int DBG, int U>
+struct OutPlan {
+    static constexpr bool ACT = U >= 0 && U < 15 && !(DBG & 4);
+    static constexpr bool TWO = ACT && U == 0;
+    static constexpr int J = U == 0 ? 0 : U + 1;
+    static constexpr int T = ACT ? 8 + J / 2 : 8, HS = ACT ? J % 2 : 0;
+};
+
 template <int DBG, int U>
 __device__ __forceinline__ void out_fetch(const float *bias_pend, int h, OutState &st) {
-    if constexpr (U < 8 && !(DBG & 4)) {
-        act_fetch<8 + U, 0, false>(bias_pend, bias_pend, h, st.in[U & 1][0]);
-        act_fetch<8 + U, 1, false>(bias_pend, bias_pend, h, st.in[U & 1][1]);
-    }
+    using P = OutPlan<DBG, U>;
+    if constexpr (P::ACT) act_fetch<P::T, P::HS, false>(bias_pend, bias_pend, h, st.in[U & 1][0]);
+    if constexpr (P::TWO) act_fetch<P::T, 1, false>(bias_pend, bias_pend, h, st.in[U & 1][1]);
 }
 
 template <int DBG, int U>
@@ -1383,9 +1443,9 @@ __device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8
     constexpr int UN = U + RD - 1;
     constexpr bool PF = UN < UNITS && !(DBG & 8);
     const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
-    // lower half -> fragments 8..15, one whole fragment per unit over units 0..7 (fragment 8+k is needed at unit 8+k)
-    constexpr bool ACT = U < 8 && !(DBG & 4);
-    constexpr int T = ACT ? 8 + U : 8;
+    using P = OutPlan<DBG, U>;
+    constexpr bool ACT = P::ACT, TWO = P::TWO;
+    constexpr int T = P::T, HS = P::HS;
     ActRegs g0, g1;
     half8(&a)[4] = st.ring[U % RD];
     half8(&nx)[4] = st.ring[UN % RD];
@@ -1395,7 +1455,8 @@ __device__ __forceinline__ void out_unit(char *lds, Ring &r, OutState &st, half8
     out_fetch<DBG, U + 1>(bias_pend, h, st);
 #define SDN_STAGE(K) \
     if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
-    if constexpr (ACT) { act_stage<T, 0, false, K>(acc, in0, bh, bl, part, g0); act_stage<T, 1, false, K>(acc, in1, bh, bl, part, g1); } \
+    if constexpr (ACT) act_stage<T, HS, false, K>(acc, in0, bh, bl, part, g0); \
+    if constexpr (TWO) act_stage<T, 1, false, K>(acc, in1, bh, bl, part, g1); \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
     col[0] = mfma16(a[0], bh[U], col[0]);
@@ -1430,6 +1491,19 @@ __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], h
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
     out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, col, bias_pend, h, part);
+}
+
+// DBG & 512 (timing experiment, ablation builds): cycles of workgroup-thread 0 per segment of a pass, summed in LDS --
+// 0 inputs (encode stage / staging), 1 fc_1, 2..6 fc_2..fc_6, 7 fc_out_c, 8 volume rendering, 9 everything between passes of
+// different groups; 10 = passes.  s_memtime is an SMEM operation: the compiler waits lgkmcnt(0) for it, which is only stricter
+// than the hand-counted LDS waits around it (segment boundaries have no fragment reads in flight).
+template <int DBG>
+__device__ __forceinline__ void seg_tick(char *lds, int idx, unsigned &tprev) {
+    if constexpr (DBG & 512) {
+        const unsigned now = (unsigned)__builtin_readcyclecounter();
+        if (threadIdx.x == 0) reinterpret_cast<unsigned *>(lds + LDS_TIMERS)[idx] += now - tprev;
+        tprev = now;
+    }
 }
 
 // CT = number of split terms of the colour layers fc_5 / fc_6 (3, or 2 = without the Whi.Xlo products)
@@ -1483,6 +1557,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     // loop-carried, and hipcc keeps loop-carried values in VGPRs, i.e. copies them out of the AGPRs right behind the
     // load -- before the data has landed.  The kernel's own allocation stays below a190 (tools/check_lds_hazards.py
     // verifies that no other instruction touches a[190:255]).
+    unsigned t_seg = 0;
+    if constexpr (DBG & 512) {
+        if (threadIdx.x < 16) reinterpret_cast<unsigned *>(lds + LDS_TIMERS)[threadIdx.x] = 0u;
+        t_seg = (unsigned)__builtin_readcyclecounter();
+    }
     long pf_tc = -1;            // pass whose inputs sit in a[190:255] (wave-uniform), -1: none
     unsigned long long t_stage = 0, t_kernel0 = 0;
     unsigned n_pass = 0;
@@ -1536,6 +1615,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) mx.bm[k] = 0.f;
             }
+            seg_tick<DBG>(lds, 9, t_seg);
             const float *fin = p.feat + (tc * 8 * 64 + lane) * 8;
             unsigned long long t_in0 = 0;
             if constexpr (DBG & 128) t_in0 = __builtin_readcyclecounter();
@@ -1626,6 +1706,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 t_stage += __builtin_readcyclecounter() - t_in0;
                 n_pass++;
             }
+            if constexpr (DBG & 512) asm volatile("s_waitcnt vmcnt(0)" ::"v"(bh[7]), "v"(bl[7]) : "memory");
+            seg_tick<DBG>(lds, 0, t_seg);
             float part = 0.f;
             const float *wsig = cst + C_WSIGMA;
             // ---- fc_1: 8 k-steps; fragments 0..6 of its upper half are activated behind its own lower half, fragment 7
@@ -1633,6 +1715,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             const float *bias1 = cst + C_LABEL_BIAS + lab * HID;
             layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, bias1, bias1, wsig, h, part);
             act_step<7, false>(acc, bias1, wsig, h, bh, bl, part);   // fragments 0..6 were activated inside the layer
+            seg_tick<DBG>(lds, 1, t_seg);
             // ---- fc_2 .. fc_6.  fc_4 (l == 2) feeds the density head (layers.py:114): its upper half is activated
             //      inside l == 2, its lower half as the pending work of l == 3 ----------------------------------------
 #pragma unroll 1
@@ -1651,6 +1734,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     else if (CT != 3 && l == 4) layer8<DBG, 16, true, false, false, CT, CT == 3, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
                     else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
                 }
+                seg_tick<DBG>(lds, 2 + l, t_seg);
             }
             // ---- fc_out_c ------------------------------------------------------------------------------------------
             {   // inputs of the next pass of this wave: the next step of this tile, or the first step of its next group
@@ -1687,19 +1771,20 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             col[0] = bias_block<0>(cst + C_BC, h);
             col[1] = bias_block<1>(cst + C_BC, h);
             layer_out<DBG>(lds, r, bh, bl, acc, col, cst + C_BETA + 4 * HID, h, part);
+            seg_tick<DBG>(lds, 7, t_seg);
             const float sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
             // ---- volume rendering (mc_utils.py:154-161) over the 4 samples of each ray in this pass ---------------
             const float fe = fmaxf(sigma, 0.f) * dist;
             float incl = fe;
-            float up = __shfl_up(incl, 1, 4);
+            float up = quad_dpp<QUAD_UP1>(incl);
             if (q >= 1) incl += up;
-            up = __shfl_up(incl, 2, 4);
+            up = quad_dpp<QUAD_UP2>(incl);
             if (q >= 2) incl += up;
-            float ex = __shfl_up(incl, 1, 4);
+            float ex = quad_dpp<QUAD_UP1>(incl);
             if (q == 0) ex = 0.f;
             const float excl = carry + ex;
             const float wgt = (1.f - __expf(-fe)) * __expf(-excl);
-            carry += __shfl(incl, 3, 4);
+            carry += quad_dpp<QUAD_LAST>(incl);
             tsum += wgt;
 #pragma unroll
             for (int ib = 0; ib < 2; ib++)
@@ -1707,14 +1792,19 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 for (int rr = 0; rr < 16; rr++) {
                     const float rgb = fminf(fmaxf(col[ib][rr], -1.f), 1.f) + 1.f;  // scenedreamer.py:408
                     float v = wgt * rgb;
-                    v += __shfl_xor(v, 1);   // sum over the 4 samples of the ray held by this quad
-                    v += __shfl_xor(v, 2);
+                    v += quad_dpp<QUAD_XOR1>(v);   // sum over the 4 samples of the ray held by this quad
+                    v += quad_dpp<QUAD_XOR2>(v);
                     if ((rr >> 2) == q) outq[ib][rr & 3] += v;
                 }
             // ---- early ray termination (north star: wavefront ballots): once the transmittance exp(-carry) of EVERY ray of
             //      the workgroup's 32 is below eps, the remaining samples can change net_out by at most 2 eps (their weights
             //      sum to < eps and that mass goes to the sky term instead): skip the group's remaining passes.  The
             //      decision is a wave ballot combined over the 4 waves, because they share the weight ring / barriers.
+            if constexpr (DBG & 512) {
+                asm volatile("" ::"v"(outq[0][0]), "v"(outq[1][3]), "v"(carry), "v"(tsum));
+                seg_tick<DBG>(lds, 8, t_seg);
+                if (threadIdx.x == 0) reinterpret_cast<unsigned *>(lds + LDS_TIMERS)[10] += 1u;
+            }
             n_done = ch + 1;
             if (p.term_depth > 0.f && ch + 1 < p.nch) {
                 const bool opaque = !ray_ok || (flag & 1) || carry > p.term_depth;
@@ -1731,12 +1821,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         if (p.passes && threadIdx.x == 0) p.passes[grp] = (uint8_t)n_done;   // passes this group went through (tests / bench)
 
         // ---- blend the sky, store ---------------------------------------------------------------------------------
-        tsum += __shfl_xor(tsum, 1);
-        tsum += __shfl_xor(tsum, 2);
+        tsum += quad_dpp<QUAD_XOR1>(tsum);
+        tsum += quad_dpp<QUAD_XOR2>(tsum);
         if constexpr (FUSED) {   // nosky = the ray's last intersection is a voxel, or one of its samples lies at world x <= 1 (:335, :382)
             int g = (int)gnd;
-            g |= __shfl_xor(g, 1);
-            g |= __shfl_xor(g, 2);
+            g |= quad_dpp<QUAD_XOR1>(g);
+            g |= quad_dpp<QUAD_XOR2>(g);
             const bool last_hit = ray_ok && enc.voxel_id[(size_t)rr * enc.M + (enc.M - 1)] != 0;
             if (last_hit || g) flag |= 2;
         }
@@ -1770,6 +1860,10 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     if (p.ticket && threadIdx.x == 0 && atomicAdd(p.ticket + 1, 1) == (int)gridDim.x - 1) {
         p.ticket[0] = 0;
         p.ticket[1] = 0;
+    }
+    if constexpr (DBG & 512) {   // per-segment cycles of this workgroup's thread 0 into its first net_out row (floats 3..13)
+        __syncthreads();
+        if (threadIdx.x < 11) p.net_out[(size_t)(blockIdx.x * 4) * OUTC + 3 + threadIdx.x] = (float)reinterpret_cast<unsigned *>(lds + LDS_TIMERS)[threadIdx.x];
     }
     if constexpr (DBG & 128) {   // timing experiment: (input-staging cycles, total cycles, passes) of this wave into net_out
         if (lane == 0) {
@@ -2251,6 +2345,12 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
         case 32: hipLaunchKernelGGL((mlp_kernel<32, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;  // colour layers without Wlo.X
         case 64: hipLaunchKernelGGL((mlp_kernel<64, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;  // ... without Whi.Xlo
         case 96: hipLaunchKernelGGL((mlp_kernel<96, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;  // ... Whi.Xhi only
+        case 512: hipLaunchKernelGGL((mlp_kernel<512, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // per-segment timers
+        case 515: hipLaunchKernelGGL((mlp_kernel<512, 3>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+        case 513: hipLaunchKernelGGL((mlp_kernel<513, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break; // timers + one ablation
+        case 514: hipLaunchKernelGGL((mlp_kernel<514, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+        case 516: hipLaunchKernelGGL((mlp_kernel<516, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
+        case 520: hipLaunchKernelGGL((mlp_kernel<520, 6>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); break;
 #endif
         default:
             if (colour_terms == 2) hipLaunchKernelGGL((mlp_kernel<0, 2>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
@@ -2278,6 +2378,12 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
     p.enc.win = p.win;
     SDN_REQUIRE(colour_terms != 2, "sdn_field_render: colour_terms must be 3 or 6 (the 2-term profile exists for sdn_field_mlp only)");
     const int wg = mlp_workgroups(p, n_workgroups);
+#ifdef SDN_MLP_ABLATION
+    if (const char *e = getenv("SDN_MLP_DBG")) {   // timing experiments only
+        if (atoi(e) == 512) { hipLaunchKernelGGL((mlp_kernel<512, 6, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); return sdn::check_launch("sdn_field_render"); }
+        if (atoi(e) == 515) { hipLaunchKernelGGL((mlp_kernel<512, 3, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); return sdn::check_launch("sdn_field_render"); }
+    }
+#endif
     if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((mlp_kernel<0, 3, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_render");
