@@ -1574,6 +1574,15 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     // group's last).  Groups are independent, so net_out does not depend on the schedule.
     volatile int *flags = reinterpret_cast<volatile int *>(lds + LDS_FLAGS);
     int grp = blockIdx.x, grp_next = blockIdx.x + (int)gridDim.x;
+    // FUSED: the first intersection of this lane's ray in group g (0 = none / no ray).  The next group's is loaded at the
+    // START of the current one, so a group does not begin with an exposed round trip to memory
+    auto first_vox = [&](int g) -> int {
+        const int t = g * 4 + wave, ry = t * RAYS_PER_TILE + (j >> 2);
+        if (!(g < n_groups && t < p.n_tiles && ry < p.R)) return 0;
+        return enc.voxel_id[(size_t)enc.win.src(ry) * enc.M];
+    };
+    int vox_cur = 0;
+    if constexpr (FUSED) vox_cur = first_vox(grp);
     while (grp < n_groups) {
         const int tile = grp * 4 + wave;
         const bool tile_ok = tile < p.n_tiles;
@@ -1584,8 +1593,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         const int rl = ray_ok ? ray : p.R - 1;            // FUSED: local ray / the same ray in the frame-wide arrays
         const int rr = FUSED ? enc.win.src(rl) : 0;
         uint8_t flag;                                      // bit 0 sky_only, bit 1 nosky (FUSED: bit 1 is known at the group's end)
-        if constexpr (FUSED) flag = (ray_ok && enc.voxel_id[(size_t)rr * enc.M] != 0) ? (uint8_t)0 : (uint8_t)1;   // scenedreamer.py:337
-        else flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
+        int vox_nxt = 0;
+        if constexpr (FUSED) {
+            flag = vox_cur != 0 ? (uint8_t)0 : (uint8_t)1;   // scenedreamer.py:337
+            vox_nxt = first_vox(grp_next);
+        } else flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
         bool gnd = false;                                  // FUSED: any sample of the ray at world x <= 1 (:380)
         int drawn = grp_next + (int)gridDim.x;            // the group after next: static stride, or ...
         if (p.ticket && threadIdx.x == 0) drawn = 2 * (int)gridDim.x + atomicAdd(p.ticket, 1);   // ... the next undrawn one
@@ -1852,6 +1864,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         }
         grp = grp_next;
         grp_next = grp_next2;
+        vox_cur = vox_nxt;
     }
     // the ring runs DMA_AHEAD slots ahead of the last pass: let it land before the LDS is released
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -7,6 +7,7 @@
 // 4 waves per workgroup, one workgroup per CU, every CU busy.  hipcc --offload-arch=gfx950 -O3 tools/unit_cost_ubench.hip -o tools/unit_cost_ubench
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8v __attribute__((ext_vector_type(8)));
@@ -123,6 +124,50 @@ void run(float *out, half8 *in, long long *cyc) {
            (double)c / (iters * 3.0), nm * 32);
 }
 
+
+// ---- does switching between v_mfma_f32_32x32x16_f16 and v_mfma_scale_f32_32x32x64_f8f6f4 cost anything?  RF f16 MFMAs then RX fp6
+// MFMAs, repeated; 4 rotating accumulators each; nothing else in the loop
+template <int RF, int RX>
+__global__ __launch_bounds__(256, 1) void ksw(float *out, const half8 *in, int iters, long long *cyc) {
+    const int lane = threadIdx.x & 63;
+    half8 a = in[lane], b = in[64 + lane];
+    const u32x4v bw = __builtin_bit_cast(u32x4v, b);
+    const i32x8v B6 = {(int)bw[0], (int)bw[1], (int)bw[2], (int)bw[3], (int)bw[0], (int)bw[1], 0, 0};
+    f32x16 acc[4];
+    for (int i = 0; i < 4; i++)
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+    long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int m = 0; m < RF; m++) {
+            acc[m % 4] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[m % 4], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int m = 0; m < RX; m++) {
+            acc[m % 4] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(B6, B6, acc[m % 4], 2, 2, 0, 127, 0, 127);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+    for (int i = 0; i < 4; i++)
+        for (int r = 0; r < 16; r++) s += acc[i][r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
+template <int RF, int RX>
+void run_sw(float *out, half8 *in, long long *cyc) {
+    const int iters = 96000 / (RF + RX);
+    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL((ksw<RF, RX>), dim3(256), dim3(256), 0, 0, out, in, iters, cyc);
+    hipDeviceSynchronize();
+    long long c;
+    hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    printf("%3d x f16 MFMA then %3d x fp6 MFMA, repeated: %6.1f cycles per MFMA (32 = matrix pipe busy)\n", RF, RX, (double)c / ((double)iters * (RF + RX)));
+}
+
 #define COL(K, NL) \
     run<K, 0, NL, 9>(out, in, cyc); run<K, 6, NL, 9>(out, in, cyc); run<K, 12, NL, 9>(out, in, cyc); run<K, 18, NL, 9>(out, in, cyc); \
     run<K, 24, NL, 9>(out, in, cyc); run<K, 30, NL, 9>(out, in, cyc); run<K, 36, NL, 9>(out, in, cyc); run<K, 42, NL, 9>(out, in, cyc); \
@@ -137,6 +182,11 @@ int main() {
     hipMalloc(&in, 128 * 16);
     hipMalloc(&cyc, 8);
     hipMemset(in, 0, 128 * 16);
+    if (getenv("UC_SWITCH")) {
+        run_sw<64, 0>(out, in, cyc); run_sw<0, 64>(out, in, cyc); run_sw<64, 32>(out, in, cyc); run_sw<16, 8>(out, in, cyc); run_sw<4, 2>(out, in, cyc);
+        run_sw<2, 1>(out, in, cyc); run_sw<1, 1>(out, in, cyc); run_sw<8, 8>(out, in, cyc);
+        return 0;
+    }
     ROWS(0) ROWS(1) ROWS(2)
     run<0, 24, 0, 1>(out, in, cyc); run<0, 24, 0, 2>(out, in, cyc); run<0, 24, 0, 3>(out, in, cyc); run<0, 24, 0, 4>(out, in, cyc);
     run<0, 24, 0, 5>(out, in, cyc); run<0, 24, 0, 6>(out, in, cyc); run<0, 24, 0, 7>(out, in, cyc); run<0, 24, 0, 8>(out, in, cyc);
