@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256, 1) void shapeA(float *out, const half8 *in, co
     for (int s = 0; s < 16; s++) { bh[s] = in[lane + 64 * s]; bl[s] = in[lane + 64 * (16 + s)]; }
     for (int i = 0; i < 8; i++) for (int e = 0; e < 16; e++) acc[i][e] = 0.f;
     int pc = 0, pn = 1;
+    const long long t_begin = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int l = 0; l < layers; l++) {
         // the first two units' fragments (the register ring runs two units ahead inside a layer)
@@ -188,6 +189,8 @@ __global__ __launch_bounds__(256, 1) void shapeA(float *out, const half8 *in, co
     for (int i = 0; i < 8; i++) for (int e = 0; e < 16; e++) s += acc[i][e];
     for (int i = 0; i < 16; i++) s += (float)bh[i][0] + (float)bl[i][1];
     out[blockIdx.x * 256 + threadIdx.x] = s;
+    // shader-clock cycles per layer of workgroup 0 (shape A only): separates the schedule (cycles) from the clock the chip holds
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[256 * 256] = (float)(__builtin_readcyclecounter() - t_begin) / (float)layers;
 }
 
 // ================================================================================================= shape B
@@ -299,6 +302,9 @@ static void run(const char *name, K kernel, int threads, float *out, half8 *in, 
         best = ms < best ? ms : best;
     }
     const double us_layer = best * 1e3 / layers;
+    float cyc = 0.f;
+    if (threads == 256) hipMemcpy(&cyc, out + 256 * 256, 4, hipMemcpyDeviceToHost);
+    if (threads == 256) printf("    %.0f shader cycles per layer (12288 = matrix pipe alone) -> %.2f GHz held\n", cyc, cyc / us_layer * 1e-3);
     // 128 samples per CU and layer; 2 * 256 * 256 FLOP per sample and layer (algorithmic), x3 issued
     printf("%-34s %8.3f us per layer  -> %6.1f TFLOP/s algorithmic on 256 CUs (%5.1f %% of 12288 cycles @2.4 GHz)\n", name, us_layer,
            128.0 * 2 * 256 * 256 * 256 / us_layer * 1e-6, 100.0 * 12288 / 2.4e3 / us_layer);
