@@ -263,6 +263,19 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms,
              void *out_hi, void *out_lo, float *out_f32, const float *proj_w, const float *proj_b, float *out_img, int H,
              int W, int n_workgroups, sdn_stream_t stream);
 
+/* The tail of RenderCNN.forward as ONE kernel: img = tanh(conv4(LeakyReLU(y + conv4b(LeakyReLU(conv4a(y))))))
+ * (imaginaire/generators/gancraft_base.py:219-225, tanh :603) -- the per-pixel 256 -> 256 -> 256 -> 3 chain evaluated
+ * register-resident on the field MLP's layer machinery (3-term f16 split everywhere): the 256-channel activation is read
+ * ONCE and never written.  Same result as  sdn_conv(conv4a) -> sdn_conv(conv4b, resid = y, proj = conv4)  to f32 rounding.
+ *   in_hi / in_lo: y as f16 planes (the layout of sdn_conv);  out_img dev f32 [3][H*W]
+ *   packed: sdn_conv_chain_packed_weight_bytes() bytes from sdn_conv_chain_pack_weights (w4a, w4b dev f32 [256,256]; w4 dev f32 [3,256])
+ *   consts dev f32 [sdn_conv_chain_consts_floats()]: conv4a.bias[256] | conv4b.bias[256] | conv4.bias padded with zeros to 64 */
+size_t sdn_conv_chain_packed_weight_bytes(void);
+size_t sdn_conv_chain_consts_floats(void);
+int sdn_conv_chain_pack_weights(const float *w4a, const float *w4b, const float *w4, void *packed, sdn_stream_t stream);
+int sdn_conv_chain(const void *in_hi, const void *in_lo, const void *packed, const float *consts, float *out_img, int H, int W,
+                   int n_workgroups, sdn_stream_t stream);
+
 /* Sky MLP for every ray + per-feature sum over rays: SKYMLP.forward(positional_encoding(raydirs, 5, incl_orig), z)
  * (imaginaire/generators/gancraft_base.py:150-169; the frame mean of scenedreamer.py:592-598 = column sums of sky_partial / n_rays).
  * consts (sdn_sky_consts_floats floats): [fc1.bias + fc_z_a(z) : 256][fc2..fc5 bias : 4x256][fc_out_c.bias : 64];

@@ -1,7 +1,9 @@
 """Host side of the MFMA render CNN (csrc/cnn.hip): RenderCNN.forward + tanh
-(imaginaire/generators/gancraft_base.py:202-225, :588-603).  Seven launches of one kernel family: conv1 (1x1, 64->256),
-conv2a/2b/3a/3b (3x3), conv4a/4b (1x1) with conv4 (256->3) + tanh folded into conv4b's epilogue; activations travel
-as f16 hi/lo planes.
+(imaginaire/generators/gancraft_base.py:202-225, :588-603).  Six launches: conv1 (1x1, 64->256),
+conv2a/2b/3a/3b (3x3), then the tail conv4a -> conv4b (+ residual) -> conv4 -> tanh as ONE register-resident chain on the
+field MLP's layer machinery (`sdn_conv_chain`, csrc/field.hip: the 256-channel activation is read once and never written;
+`chain = False`: conv4a / conv4b as conv_kernel launches with conv4 + tanh folded into conv4b's epilogue); activations
+travel as f16 hi/lo planes.
 
 Precision profile (`terms3x3`): the 1x1 layers always use the 3-term f16 split; the four 3x3 layers use either the
 3-term split (< 2e-5 from the fp32 CNN) or ONE term (Whi.Xhi, both rounded to nearest: a third of the MFMAs; measured
@@ -9,6 +11,7 @@ image error vs the fp32 CNN ~7e-5 rms / < 5e-4 max on the synthetic weights, too
 is lossy in a weight-dependent way, so which one runs is decided per style by Renderer.mfma_cnn (a measured gate), not
 here; this class takes the decision as `terms3x3`."""
 import ctypes
+import os
 
 import torch
 
@@ -19,9 +22,12 @@ _LAYERS = {"conv1": (64, 1), "conv2a": (256, 9), "conv2b": (256, 9), "conv3a": (
 
 
 class MfmaCNN:
-    def __init__(self, R, terms3x3):
+    def __init__(self, R, terms3x3, chain=None):
         self.R = R
         assert terms3x3 in (1, 3)
+        if chain is None:
+            chain = os.environ.get("SDN_CNN_CHAIN", "1") != "0"
+        self.chain = bool(chain)
         self.terms = {n: (terms3x3 if taps == 9 else 3) for n, (_, taps) in _LAYERS.items()}
         lib = capi.lib()
         w = R.w
@@ -37,6 +43,19 @@ class MfmaCNN:
         self.w4 = w["denoiser.conv4.weight"].reshape(3, 256).contiguous()
         self.b4 = w["denoiser.conv4.bias"].contiguous()
         self._planes = {}
+        if self.chain:
+            with torch.cuda.device(R.dev):
+                self.chain_packed = torch.empty(lib.sdn_conv_chain_packed_weight_bytes(), dtype=torch.uint8, device=R.dev)
+                w4a = w["denoiser.conv4a.weight"].reshape(256, 256).contiguous()
+                w4b = w["denoiser.conv4b.weight"].reshape(256, 256).contiguous()
+                capi.check(lib.sdn_conv_chain_pack_weights(w4a.data_ptr(), w4b.data_ptr(), self.w4.data_ptr(),
+                                                           self.chain_packed.data_ptr(), capi.current_stream(R.dev)),
+                           "sdn_conv_chain_pack_weights")
+                c = torch.zeros(lib.sdn_conv_chain_consts_floats(), device=R.dev)
+                c[0:256] = w["denoiser.conv4a.bias"]
+                c[256:512] = w["denoiser.conv4b.bias"]
+                c[512:515] = self.b4
+                self.chain_consts = c
 
     def _buffers(self, H, W):
         key = (H, W)
@@ -95,6 +114,12 @@ class MfmaCNN:
         self._conv(B, "conv2b", H, W, bias=bias("conv2b"), resid_planes=A, mod=(a[0], a[1]), dst=A)
         self._conv(A, "conv3a", H, W, bias=bias("conv3a"), dst=inner)
         self._conv(B, "conv3b", H, W, bias=bias("conv3b"), resid_planes=A, mod=(a[2], a[3]), dst=A)
+        if self.chain:
+            with torch.cuda.device(R.dev):
+                capi.check(capi.lib().sdn_conv_chain(A[0].data_ptr(), A[1].data_ptr(), self.chain_packed.data_ptr(),
+                                                     self.chain_consts.data_ptr(), img.data_ptr(), H, W, 0,
+                                                     capi.current_stream(R.dev)), "sdn_conv_chain")
+            return img
         self._conv(A, "conv4a", H, W, bias=bias("conv4a"), dst=B)
         self._conv(B, "conv4b", H, W, bias=bias("conv4b"), resid_planes=A, proj=(self.w4, self.b4), img=img)
         return img

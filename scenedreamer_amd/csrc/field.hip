@@ -2118,6 +2118,315 @@ __global__ void mfma_probe_kernel(const float *A, const float *B, float *C) {
     for (int r = 0; r < 16; r++) C[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + j] = c[r];
 }
 
+
+// =====================================================================================================
+// Render CNN tail as ONE register-resident chain:  conv4a -> LeakyReLU -> conv4b + y -> LeakyReLU -> conv4 -> tanh
+// (RenderCNN.forward, imaginaire/generators/gancraft_base.py:219-225; tanh :603)
+// =====================================================================================================
+// The three 1x1 convolutions are a per-pixel MLP 256 -> 256 -> 256 -> 3, i.e. exactly what the layer machinery above evaluates
+// for the field samples: 32 pixels per wave as MFMA columns, all 256 channels of a pixel in the wave's registers, weights
+// through the LDS ring, 3-term f16 split.  As three conv_kernel launches (cnn.hip) the tail is bound by memory: it writes and
+// re-reads the 256-channel activation twice (conv4a 0.30 ms + conv4b 0.42 ms per 960x540 frame for 2.2 GB); as a chain it reads
+// the activation planes once and writes 3 floats per pixel.
+//   input:   the running activation y as f16 hi / lo planes [16 chunks][Hb*Wb pixels][16 channels] (cnn.hip's layout).  A lane
+//            loads its pixel's channels in the accumulator (C/D) order -- fragment T, element e = channel 16 T + (e & 3) +
+//            8 (e >> 2) + 4 h: two 8-byte pieces per chunk and plane -- so conv4a's weights are packed like a hidden layer's
+//            (kmap_hidden) and the RESIDUAL of conv4b is lane-local: the value added to accumulator register 8 Q + 4 HS + e of
+//            row block IB is element 4 HS + e of the lane's own input fragment T = 2 IB + Q.  The input fragments are
+//            overwritten by conv4a's activations, so a copy (yh / yl) stays live until conv4b's activation has consumed it;
+//            hipcc parks what does not fit into the 256 VGPRs in the AGPRs the accumulators leave free.
+//   layers:  conv4a = layer8 (upper half activated behind its own lower half, lower half behind conv4b's head);
+//            conv4b = the same with act_stage_res for its own halves (bias + residual, then the shared stages);
+//            conv4  = layer_out's units with conv4b's lower half as the pending work; rows 0..2 of row block 0 are the image.
+constexpr int CHAIN_SLOTS = (64 + 64 + 16) / UNITS_PER_SLOT;    // 18 ring slots per 128 pixels
+constexpr size_t CHAIN_FRAGS = 2 * LH_FRAGS + LO_FRAGS;
+constexpr int CC_B4A = 0, CC_B4B = HID, CC_B4 = 2 * HID, CC_TOTAL = 2 * HID + OUTC;
+
+struct ChainParams {
+    const _Float16 *yh, *yl;   // input planes
+    const half8 *wpk;          // conv4a | conv4b | conv4 (64 rows, 3 used) in the packed unit order
+    const float *consts;       // CC_TOTAL floats: conv4a.bias | conv4b.bias | conv4.bias padded to 64
+    float *img;                // [3][H*W]
+    int32_t H, W, Wb;
+    long chunk_bytes;          // Hb*Wb*32: byte stride between channel chunks of a plane
+    int32_t tiles_per_row, n_tiles;   // 32-pixel runs of one image row
+};
+
+struct ChainPackParams {
+    const float *w4a, *w4b, *w4;   // [256,256], [256,256], [3,256]
+    half8 *out;
+};
+
+__global__ __launch_bounds__(256) void chain_pack_kernel(const ChainPackParams p) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;   // one thread per (layer, unit, row block of the pair, lane)
+    const size_t nh = 64 * 2 * 64, no = 16 * 2 * 64;
+    if (g >= 2 * nh + no) return;
+    const int layer = g < nh ? 0 : g < 2 * nh ? 1 : 2;
+    size_t r = g - (size_t)layer * nh;
+    const float *W = layer == 0 ? p.w4a : layer == 1 ? p.w4b : p.w4;
+    const size_t base = (size_t)layer * LH_FRAGS;
+    const int lane = (int)(r % 64); r /= 64;
+    const int sel = (int)(r % 2);
+    const int u = (int)(r / 2);
+    int s, ib0;
+    unit_coords(layer == 2 ? 2 : 8, 16, u, s, ib0);
+    const int row = 32 * (ib0 + sel) + (lane & 31), h = lane >> 5;
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        // conv4b / conv4 consume a' = LeakyReLU(x) / 0.4 (act_stage); conv4a consumes y itself
+        const float w = (layer == 2 && row >= 3) ? 0.f : W[(size_t)row * HID + kmap_hidden(s, h, e)];
+        const float v = w * (layer == 0 ? 1.0f : ACT_SCALE);
+        const _Float16 vh = (_Float16)v;
+        hi[e] = vh;
+        lo[e] = (_Float16)(v - (float)vh);
+    }
+    p.out[base + ((size_t)u * 4 + 2 * sel + 0) * 64 + lane] = hi;
+    p.out[base + ((size_t)u * 4 + 2 * sel + 1) * 64 + lane] = lo;
+}
+
+// act_stage with the residual: stage 1 adds the bias and y (hi + lo)
+template <int T, int HS, int STAGE>
+__device__ __forceinline__ void act_stage_res(const f32x16 (&acc)[8], const ActIn &in, half8 (&bh)[16], half8 (&bl)[16],
+                                              const half8 (&yh)[16], const half8 (&yl)[16], float &part, ActRegs &g) {
+    act_stage<T, HS, false, STAGE, true>(acc, in, bh, bl, part, g);
+    if constexpr (STAGE == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) g.y[e] += (float)yh[T][4 * HS + e] + (float)yl[T][4 * HS + e];
+    }
+}
+
+// conv4b: layer8_unit's 3-term path (half-rate ActPlan) with the residual in the activation of its OWN upper half
+template <int DBG, int U>
+__device__ __forceinline__ void chain_b_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
+                                             const half8 (&yh)[16], const half8 (&yl)[16], const float *bias,
+                                             const float *bias_pend, int h, float &part) {
+    constexpr int UNITS = 64, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
+    using P = ActPlan<DBG, 16, true, false, false, U, true>;
+    if constexpr (U % UPS == 0 && U != 0) {
+        st.pos_cur = ring_acquire<DBG>(lds, r);
+        st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    }
+    constexpr int UN = U + RD - 1;
+    constexpr bool PF = UN < UNITS;
+    const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
+    constexpr int S = P::S, IB = 4 * P::HALF + 2 * (P::REM & 1);
+    half8(&a)[4] = st.ring[U % RD];
+    half8(&nx)[4] = st.ring[UN % RD];
+    const ActIn &in = st.in[P::SLOT];
+    constexpr bool PF_PREV = U == 0 || (U - 1 + RD - 1) < UNITS;
+    lds_wait<PF_PREV ? 4 : 0>();
+    layer8_fetch<DBG, 16, true, false, false, U + 1, true>(bias, bias_pend, bias, h, st);
+#define SDN_STAGE(K) \
+    if constexpr (U % UPS < PIECES / 4 && K < 4) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
+    if constexpr (P::stage(K) >= 0 && P::PEND) act_stage<P::T, P::HS, false, P::stage(K) < 0 ? 0 : P::stage(K), true>(acc, in, bh, bl, part, st.g); \
+    if constexpr (P::stage(K) >= 0 && P::OWN) act_stage_res<P::T, P::HS, P::stage(K) < 0 ? 0 : P::stage(K)>(acc, in, bh, bl, yh, yl, part, st.g); \
+    if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (S == 0) acc[IB] = mfma16(a[0], bh[S], zero16());
+    else acc[IB] = mfma16(a[0], bh[S], acc[IB]);
+    SDN_STAGE(0)
+    if constexpr (S == 0) acc[IB + 1] = mfma16(a[2], bh[S], zero16());
+    else acc[IB + 1] = mfma16(a[2], bh[S], acc[IB + 1]);
+    SDN_STAGE(1)
+    acc[IB] = mfma16(a[1], bh[S], acc[IB]);
+    SDN_STAGE(2)
+    acc[IB + 1] = mfma16(a[3], bh[S], acc[IB + 1]);
+    SDN_STAGE(3)
+    acc[IB] = mfma16(a[0], bl[S], acc[IB]);
+    SDN_STAGE(4)
+    acc[IB + 1] = mfma16(a[2], bl[S], acc[IB + 1]);
+    SDN_STAGE(5)
+#undef SDN_STAGE
+}
+
+template <int DBG, int... Us>
+__device__ __forceinline__ void chain_b_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st, half8 (&bh)[16],
+                                              half8 (&bl)[16], f32x16 (&acc)[8], const half8 (&yh)[16], const half8 (&yl)[16],
+                                              const float *bias, const float *bias_pend, int h, float &part) {
+    (chain_b_unit<DBG, Us>(lds, r, st, bh, bl, acc, yh, yl, bias, bias_pend, h, part), ...);
+}
+
+template <int DBG>
+__device__ __forceinline__ void chain_layer_b(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
+                                              const half8 (&yh)[16], const half8 (&yl)[16], const float *bias, const float *bias_pend,
+                                              int h, float &part) {
+    LayerState st;
+    st.pos_cur = ring_acquire<DBG>(lds, r);
+    st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    layer8_fetch<DBG, 16, true, false, false, 0, true>(bias, bias_pend, bias, h, st);
+    lds_unit<0>(r, st.pos_cur, st.ring[0]);
+    lds_unit<1>(r, st.pos_cur, st.ring[1]);
+    chain_b_units<DBG>(std::make_integer_sequence<int, 64>{}, lds, r, st, bh, bl, acc, yh, yl, bias, bias_pend, h, part);
+}
+
+// a lane's input fragment T of one plane: channels 16 T + 4 h + {0..3} and 16 T + 8 + 4 h + {0..3} of its pixel (two 8-byte pieces)
+struct ChainSrc {
+    const char *h, *l;   // hi / lo plane + this lane's byte offset inside chunk 0
+    long chunk_bytes;
+};
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+template <int T>
+__device__ __forceinline__ void chain_load(const ChainSrc &src, half8 &fh, half8 &fl) {
+    const char *ph = src.h + (long)T * src.chunk_bytes, *pl = src.l + (long)T * src.chunk_bytes;
+    const u32x2v h0 = *reinterpret_cast<const u32x2v *>(ph), h1 = *reinterpret_cast<const u32x2v *>(ph + 16);
+    const u32x2v l0 = *reinterpret_cast<const u32x2v *>(pl), l1 = *reinterpret_cast<const u32x2v *>(pl + 16);
+    fh = __builtin_bit_cast(half8, u32x4v{h0[0], h0[1], h1[0], h1[1]});
+    fl = __builtin_bit_cast(half8, u32x4v{l0[0], l0[1], l1[0], l1[1]});
+}
+
+template <int... Ts>
+__device__ __forceinline__ void chain_load_all(std::integer_sequence<int, Ts...>, const ChainSrc &src, half8 (&fh)[16], half8 (&fl)[16]) {
+    (chain_load<Ts>(src, fh[Ts], fl[Ts]), ...);
+}
+
+// conv4: out_unit with the residual in the pending activation (conv4b's lower half).  The NEXT 128 pixels' input is loaded
+// here, a layer ahead of its first use: unit U consumes fragment U for the last time, so fragment U of the next pass goes
+// out at unit U + 1 (U < 8), and fragments 8..15 go out at units 0..7 into the registers the residual copy of fragments 0..7
+// left free after conv4b.  All 64 loads are in flight by unit 8; hipcc waits for them (vmcnt(0): it cannot count across the
+// loop's back edge) in front of conv4a's first MFMA, ~8 units later.
+template <int DBG, int U>
+__device__ __forceinline__ void chain_out_unit(char *lds, Ring &r, OutState &st, half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8],
+                                               const half8 (&yh)[16], const half8 (&yl)[16], f32x16 (&col)[2], const float *bias_pend,
+                                               int h, float &part, const ChainSrc &nsrc, half8 (&nh)[16], half8 (&nl)[16]) {
+    constexpr int UNITS = 16, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
+    if constexpr (U % UPS == 0 && U != 0) {
+        st.pos_cur = ring_acquire<DBG>(lds, r);
+        st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    }
+    constexpr int UN = U + RD - 1;
+    constexpr bool PF = UN < UNITS;
+    const int pf_pos = (UN / UPS) == (U / UPS) ? st.pos_cur : st.pos_nxt;
+    using P = OutPlan<DBG, U>;
+    constexpr bool ACT = P::ACT, TWO = P::TWO;
+    constexpr int T = P::T, HS = P::HS;
+    ActRegs g0, g1;
+    half8(&a)[4] = st.ring[U % RD];
+    half8(&nx)[4] = st.ring[UN % RD];
+    const ActIn &in0 = st.in[U & 1][0], &in1 = st.in[U & 1][1];
+    constexpr bool PF_PREV = U == 0 || (U - 1 + RD - 1) < UNITS;
+    lds_wait<PF_PREV ? 4 : 0>();
+    out_fetch<DBG, U + 1>(bias_pend, h, st);
+#define SDN_STAGE(K) \
+    if constexpr (U % UPS < PIECES / 4 && K < 4) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
+    if constexpr (ACT) act_stage_res<T, HS, K>(acc, in0, bh, bl, yh, yl, part, g0); \
+    if constexpr (TWO) act_stage_res<T, 1, K>(acc, in1, bh, bl, yh, yl, part, g1); \
+    if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
+    if constexpr (U >= 1 && U <= 8 && K == 5) chain_load<(U >= 1 && U <= 8 ? U - 1 : 0)>(nsrc, nh[U >= 1 && U <= 8 ? U - 1 : 0], nl[U >= 1 && U <= 8 ? U - 1 : 0]); \
+    if constexpr (U <= 7 && K == 4) chain_load<(U <= 7 ? 8 + U : 8)>(nsrc, nh[U <= 7 ? 8 + U : 8], nl[U <= 7 ? 8 + U : 8]); \
+    __builtin_amdgcn_sched_barrier(0);
+    col[0] = mfma16(a[0], bh[U], col[0]);
+    SDN_STAGE(0)
+    col[1] = mfma16(a[2], bh[U], col[1]);
+    SDN_STAGE(1)
+    col[0] = mfma16(a[1], bh[U], col[0]);
+    SDN_STAGE(2)
+    col[1] = mfma16(a[3], bh[U], col[1]);
+    SDN_STAGE(3)
+    col[0] = mfma16(a[0], bl[U], col[0]);
+    SDN_STAGE(4)
+    col[1] = mfma16(a[2], bl[U], col[1]);
+    SDN_STAGE(5)
+#undef SDN_STAGE
+}
+
+template <int DBG, int... Us>
+__device__ __forceinline__ void chain_out_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, OutState &st, half8 (&bh)[16],
+                                                half8 (&bl)[16], const f32x16 (&acc)[8], const half8 (&yh)[16], const half8 (&yl)[16],
+                                                f32x16 (&col)[2], const float *bias_pend, int h, float &part, const ChainSrc &nsrc,
+                                                half8 (&nh)[16], half8 (&nl)[16]) {
+    (chain_out_unit<DBG, Us>(lds, r, st, bh, bl, acc, yh, yl, col, bias_pend, h, part, nsrc, nh, nl), ...);
+}
+
+template <int DBG>
+__device__ __forceinline__ void chain_layer_out(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8],
+                                                const half8 (&yh)[16], const half8 (&yl)[16], f32x16 (&col)[2], const float *bias_pend,
+                                                int h, float &part, const ChainSrc &nsrc, half8 (&nh)[16], half8 (&nl)[16]) {
+    OutState st;
+    st.pos_cur = ring_acquire<DBG>(lds, r);
+    st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
+    out_fetch<DBG, 0>(bias_pend, h, st);
+    lds_unit<0>(r, st.pos_cur, st.ring[0]);
+    lds_unit<1>(r, st.pos_cur, st.ring[1]);
+    chain_out_units<DBG>(std::make_integer_sequence<int, 16>{}, lds, r, st, bh, bl, acc, yh, yl, col, bias_pend, h, part, nsrc, nh, nl);
+}
+
+__global__ __launch_bounds__(256, 1) void chain_kernel(const ChainParams p) {
+    constexpr int DBG = 0;
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    float *cst = reinterpret_cast<float *>(lds + LDS_CONST);
+    for (int i = threadIdx.x; i < CC_TOTAL; i += 256) cst[i] = p.consts[i];
+    __syncthreads();
+
+    Ring r;
+    r.slots_per_pass = CHAIN_SLOTS;
+    r.wbytes = reinterpret_cast<const char *>(p.wpk);
+    r.g = 0;
+    r.wave = __builtin_amdgcn_readfirstlane(wave);
+    r.lane = lane;
+    r.voff = r.wave * (PIECES * 1024) + lane * 16;
+    r.lds_lane = (unsigned)(size_t)(const lds_char *)(lds + LDS_RING) + lane * 16;
+    r.src_delta = r.wave * (PIECES * 1024) - (int)(unsigned)(size_t)(const lds_char *)(lds + LDS_RING);
+#pragma unroll
+    for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl);
+    r.next_in_pass = DMA_AHEAD;
+
+    const int n_groups = (p.n_tiles + 3) >> 2;
+    // where a group's pixels are: 32 consecutive x of one image row per wave; lanes beyond the row's end (and waves beyond the
+    // last tile) evaluate a clamped pixel and store nothing
+    struct Where { int y, x; bool ok; ChainSrc src; };
+    auto where = [&](int grp) {
+        Where w;
+        const int tile = grp * 4 + wave;
+        const bool tile_ok = tile < p.n_tiles;
+        const int t = tile_ok ? tile : p.n_tiles - 1;
+        w.y = t / p.tiles_per_row;
+        w.x = (t - w.y * p.tiles_per_row) * 32 + j;
+        w.ok = tile_ok && w.x < p.W;
+        const int xc = w.x < p.W ? w.x : p.W - 1;
+        // byte offset of this lane's first 8-byte piece inside chunk 0 (pixel (y, x) of the frame is buffer pixel (y+1, x+1))
+        const long off = ((long)(w.y + 1) * p.Wb + (xc + 1)) * 32 + 8 * h;
+        w.src.h = reinterpret_cast<const char *>(p.yh) + off;
+        w.src.l = reinterpret_cast<const char *>(p.yl) + off;
+        w.src.chunk_bytes = p.chunk_bytes;
+        return w;
+    };
+    half8 bh[16], bl[16];
+    Where cur = where(blockIdx.x < n_groups ? blockIdx.x : 0);
+    chain_load_all(std::make_integer_sequence<int, 16>{}, cur.src, bh, bl);
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int grp_n = grp + (int)gridDim.x;
+        const Where nxt = where(grp_n < n_groups ? grp_n : grp);   // (the last pass re-loads its own pixels: no branch in the loads)
+        half8 yh[16], yl[16], nh[16], nl[16];
+        f32x16 acc[8];
+#pragma unroll
+        for (int T = 0; T < 16; T++) { yh[T] = bh[T]; yl[T] = bl[T]; }
+        float part = 0.f;
+        // conv4a: its upper half is activated behind its own lower half, its lower half behind conv4b's head
+        layer8<DBG, 16, false, false, false>(lds, r, bh, bl, acc, cst + CC_B4A, cst + CC_B4A, cst, h, part);
+        // conv4b (+ y): the same, every activation of ITS outputs with the residual
+        chain_layer_b<DBG>(lds, r, bh, bl, acc, yh, yl, cst + CC_B4B, cst + CC_B4A, h, part);
+        f32x16 col[2];
+        col[0] = bias_block<0>(cst + CC_B4, h);
+        col[1] = bias_block<1>(cst + CC_B4, h);
+        chain_layer_out<DBG>(lds, r, bh, bl, acc, yh, yl, col, cst + CC_B4B, h, part, nxt.src, nh, nl);
+        asm volatile("" ::"v"(col[1]));   // (row block 1 of the projection is padding)
+        // rows 0..2 of row block 0 = registers 0..2 of the h = 0 half: the image, gancraft_base.py:603
+        if (cur.ok && h == 0) {
+            const size_t o = (size_t)cur.y * p.W + cur.x;
+#pragma unroll
+            for (int c = 0; c < 3; c++) p.img[(size_t)c * p.H * p.W + o] = tanhf(col[0][c]);
+        }
+        cur.y = nxt.y; cur.x = nxt.x; cur.ok = nxt.ok;
+#pragma unroll
+        for (int T = 0; T < 16; T++) { bh[T] = nh[T]; bl[T] = nl[T]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring runs DMA_AHEAD slots ahead: let it land before the LDS is released
+    __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -2400,6 +2709,37 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
     if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((mlp_kernel<0, 3, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_render");
+}
+
+size_t sdn_conv_chain_packed_weight_bytes(void) { return CHAIN_FRAGS * sizeof(half8); }
+size_t sdn_conv_chain_consts_floats(void) { return CC_TOTAL; }
+
+int sdn_conv_chain_pack_weights(const float *w4a, const float *w4b, const float *w4, void *packed, sdn_stream_t stream) {
+    SDN_REQUIRE(w4a && w4b && w4 && packed, "sdn_conv_chain_pack_weights: null pointer");
+    ChainPackParams p;
+    p.w4a = w4a; p.w4b = w4b; p.w4 = w4; p.out = (half8 *)packed;
+    const size_t n = 2 * 64 * 2 * 64 + 16 * 2 * 64;
+    hipLaunchKernelGGL(chain_pack_kernel, dim3((unsigned)sdn::div_up<size_t>(n, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_conv_chain_pack_weights");
+}
+
+int sdn_conv_chain(const void *in_hi, const void *in_lo, const void *packed, const float *consts, float *out_img, int H, int W,
+                   int n_workgroups, sdn_stream_t stream) {
+    SDN_REQUIRE(in_hi && in_lo && packed && consts && out_img && H > 0 && W > 0, "sdn_conv_chain: bad argument");
+    ChainParams p;
+    p.yh = (const _Float16 *)in_hi; p.yl = (const _Float16 *)in_lo; p.wpk = (const half8 *)packed; p.consts = consts; p.img = out_img;
+    p.H = H; p.W = W;
+    int Hb, Wb;
+    sdn_conv_plane_dims(H, W, &Hb, &Wb);
+    p.Wb = Wb;
+    p.chunk_bytes = (long)Hb * Wb * 32;
+    p.tiles_per_row = sdn::div_up(W, 32);
+    p.n_tiles = p.tiles_per_row * H;
+    const int n_groups = sdn::div_up(p.n_tiles, 4);
+    int wg = n_workgroups > 0 ? n_workgroups : 256;
+    if (wg > n_groups) wg = n_groups;
+    hipLaunchKernelGGL(chain_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_conv_chain");
 }
 
 size_t sdn_sky_packed_weight_bytes(void) { return SKY_PACKED_FRAGS * sizeof(half8); }

@@ -133,6 +133,23 @@ def test_mfma_cnn_matches_torch_cnn(renderer, terms3x3, bound):
         assert got.shape == ref.shape and err.max().item() < bound, f"max abs err {err.max().item():.3e}"
 
 
+def test_cnn_tail_as_one_chain_equals_the_three_launches(renderer):
+    """conv4a -> conv4b (+ residual) -> conv4 -> tanh as ONE register-resident kernel (sdn_conv_chain, the field MLP's layer
+    machinery) against the same layers as conv_kernel launches: both evaluate every product as the 3-term f16 split, only the
+    f32 summation order differs.  Ragged widths (tiles of 32 pixels per row) and more tiles than workgroups."""
+    from scenedreamer_amd.cnn import MfmaCNN
+    torch.manual_seed(1)
+    for hw in ((5, 31), (37, 53), (64, 96), (300, 520)):
+        x = (torch.rand(1, hw[0], hw[1], 64, device="cuda") * 2 - 1)
+        one = MfmaCNN(renderer, 3, chain=True)(x)
+        three = MfmaCNN(renderer, 3, chain=False)(x)
+        ref = renderer.render_cnn(x)
+        d = (one - three).abs().max().item()
+        print(f"CNN tail chain vs launches {hw}: max abs diff {d:.2e}; vs torch fp32 {(one - ref).abs().max().item():.2e}")
+        assert one.shape == three.shape and d < 2e-5
+        assert (one - ref).abs().max().item() < 2e-4
+
+
 def test_cnn_precision_gate_is_measured_per_style(renderer, scene256):
     """cnn_terms3x3 = None ("auto"): the lossy 1-term 3x3 convolutions are used only when the first frame of the style shows
     them within CNN_AUTO_BOUND of the 3-term image; otherwise the 3-term kernels run.  A new style re-opens the gate."""

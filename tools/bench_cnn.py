@@ -11,7 +11,7 @@ scene = synth.make_scene(256, 3407, device=dev)
 R = Renderer(synth.make_weights(0, grid_log2_hashmap=10), scene, dev)
 R.set_style(synth.make_style(8888))
 cnn = MfmaCNN(R, int(os.environ.get("SDN_CNN_TERMS", "1")))
-H, W = 570, 990
+H, W = 548, 968   # the benchmark frame with its apron
 x = torch.rand(1, H, W, 64, device=dev) * 2 - 1
 buf = cnn._buffers(H, W)
 t_all = _time_ms(lambda: cnn(x), 5)
@@ -21,4 +21,10 @@ t_1 = _time_ms(lambda: cnn._conv(buf["b"], "conv1", H, W, bias=R.w["denoiser.con
 img = torch.empty(1, 3, H, W, device=dev)
 t_4b = _time_ms(lambda: cnn._conv(buf["b"], "conv4b", H, W, bias=R.w.get("denoiser.conv4b.bias"), resid_planes=buf["a"], proj=(cnn.w4, cnn.b4), img=img), 5)
 print(f"conv1 {t_1:.3f} ms  conv4a {t_11:.3f} ms  conv4b+proj {t_4b:.3f} ms")
+if cnn.chain:
+    from scenedreamer_amd import capi
+    t_ch = _time_ms(lambda: capi.check(capi.lib().sdn_conv_chain(buf["a"][0].data_ptr(), buf["a"][1].data_ptr(), cnn.chain_packed.data_ptr(),
+                                                                  cnn.chain_consts.data_ptr(), img.data_ptr(), H, W, 0,
+                                                                  capi.current_stream(dev)), "sdn_conv_chain"), 5)
+    print(f"conv4a -> conv4b -> conv4 as one chain {t_ch:.3f} ms (as launches: {t_11 + t_4b:.3f} ms)")
 print(f"cnn total {t_all:.3f} ms   one conv3x3 {t_conv:.3f} ms   dbg={os.environ.get('SDN_CONV_DBG','0')}")
