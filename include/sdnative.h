@@ -263,6 +263,15 @@ int sdn_conv(const void *in_hi, const void *in_lo, int cin, int taps, int terms,
              void *out_hi, void *out_lo, float *out_f32, const float *proj_w, const float *proj_b, float *out_img, int H,
              int W, int n_workgroups, sdn_stream_t stream);
 
+/* The head of RenderCNN.forward as ONE kernel: y = LeakyReLU_0.2(conv1(x) + bias) (gancraft_base.py:206), x dev f32 rows
+ * [H*W][64] (net_out), y as f16 hi / lo planes -- the same result as sdn_conv_planes_from_f32 -> sdn_conv(conv1) to f32
+ * rounding, without the 64-channel planes in between.  w1 dev f32 [256,64]; bias dev f32 [256]; the output planes are
+ * zero-filled by the caller once (only pixels of the H x W frame are written). */
+size_t sdn_conv_head_packed_weight_bytes(void);
+int sdn_conv_head_pack_weights(const float *w1, void *packed, sdn_stream_t stream);
+int sdn_conv_head(const float *x, const void *packed, const float *bias, void *out_hi, void *out_lo, int H, int W, int n_workgroups,
+                  sdn_stream_t stream);
+
 /* The tail of RenderCNN.forward as ONE kernel: img = tanh(conv4(LeakyReLU(y + conv4b(LeakyReLU(conv4a(y))))))
  * (imaginaire/generators/gancraft_base.py:219-225, tanh :603) -- the per-pixel 256 -> 256 -> 256 -> 3 chain evaluated
  * register-resident on the field MLP's layer machinery (3-term f16 split everywhere): the 256-channel activation is read

@@ -72,6 +72,9 @@ _SIGNATURES = {
     "sdn_conv_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
     "sdn_conv_planes_from_f32": (c_i, [c_p, c_i, c_p, c_p, c_i, c_i, c_p]),
     "sdn_conv": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "sdn_conv_head_packed_weight_bytes": (ctypes.c_size_t, []),
+    "sdn_conv_head_pack_weights": (c_i, [c_p, c_p, c_p]),
+    "sdn_conv_head": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "sdn_conv_chain_packed_weight_bytes": (ctypes.c_size_t, []),
     "sdn_conv_chain_consts_floats": (ctypes.c_size_t, []),
     "sdn_conv_chain_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),

@@ -1,5 +1,6 @@
 """Host side of the MFMA render CNN (csrc/cnn.hip): RenderCNN.forward + tanh
-(imaginaire/generators/gancraft_base.py:202-225, :588-603).  Six launches: conv1 (1x1, 64->256),
+(imaginaire/generators/gancraft_base.py:202-225, :588-603).  Six launches: the head (`sdn_conv_head`, csrc/field.hip: net_out
+rows -> conv1 -> LeakyReLU -> y planes in one kernel; `chain = False`: sdn_conv_planes_from_f32 + conv1 as a conv_kernel launch),
 conv2a/2b/3a/3b (3x3), then the tail conv4a -> conv4b (+ residual) -> conv4 -> tanh as ONE register-resident chain on the
 field MLP's layer machinery (`sdn_conv_chain`, csrc/field.hip: the 256-channel activation is read once and never written;
 `chain = False`: conv4a / conv4b as conv_kernel launches with conv4 + tanh folded into conv4b's epilogue); activations
@@ -56,6 +57,11 @@ class MfmaCNN:
                 c[256:512] = w["denoiser.conv4b.bias"]
                 c[512:515] = self.b4
                 self.chain_consts = c
+                self.head_packed = torch.empty(lib.sdn_conv_head_packed_weight_bytes(), dtype=torch.uint8, device=R.dev)
+                w1 = w["denoiser.conv1.weight"].reshape(256, 64).contiguous()
+                capi.check(lib.sdn_conv_head_pack_weights(w1.data_ptr(), self.head_packed.data_ptr(), capi.current_stream(R.dev)),
+                           "sdn_conv_head_pack_weights")
+                self.head_bias = w["denoiser.conv1.bias"].contiguous()
 
     def _buffers(self, H, W):
         key = (H, W)
@@ -102,12 +108,18 @@ class MfmaCNN:
         bias = lambda n: w.get(f"denoiser.{n}.bias")
         x = net_out.reshape(H * W, 64).contiguous()
         img = torch.empty(1, 3, H, W, device=R.dev)
-        with torch.cuda.device(R.dev):
-            capi.check(capi.lib().sdn_conv_planes_from_f32(x.data_ptr(), 64, B[0].data_ptr(), B[1].data_ptr(), H, W,
-                                                           capi.current_stream(R.dev)), "sdn_conv_planes_from_f32")
         # the running activation y lives in planes A (hi + lo f16 = y to 2^-22) and is updated in place by the
         # residual convolutions; planes B hold the inner activation of each residual block
-        self._conv(B, "conv1", H, W, bias=bias("conv1"), dst=A)                                    # y = act(conv1(x))
+        if self.chain:                                                                             # y = act(conv1(x))
+            with torch.cuda.device(R.dev):
+                capi.check(capi.lib().sdn_conv_head(x.data_ptr(), self.head_packed.data_ptr(), self.head_bias.data_ptr(),
+                                                    A[0].data_ptr(), A[1].data_ptr(), H, W, 0, capi.current_stream(R.dev)),
+                           "sdn_conv_head")
+        else:
+            with torch.cuda.device(R.dev):
+                capi.check(capi.lib().sdn_conv_planes_from_f32(x.data_ptr(), 64, B[0].data_ptr(), B[1].data_ptr(), H, W,
+                                                               capi.current_stream(R.dev)), "sdn_conv_planes_from_f32")
+            self._conv(B, "conv1", H, W, bias=bias("conv1"), dst=A)
         # the inner activations are consumed only by conv2b / conv3b: no lo plane when those are 1-term
         inner = (B[0], None) if self.terms["conv2b"] == 1 else B
         self._conv(A, "conv2a", H, W, bias=bias("conv2a"), dst=inner)                              # act(conv2a(y))

@@ -2427,6 +2427,129 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainParams p) {
     __builtin_amdgcn_s_barrier();
 }
 
+
+// =====================================================================================================
+// Render CNN head: net_out rows -> conv1 (1x1, 64 -> 256) -> LeakyReLU -> y as f16 hi / lo planes, in ONE kernel
+// (RenderCNN.forward, gancraft_base.py:206; replaces planes_kernel + conv_kernel<1> of cnn.hip)
+// =====================================================================================================
+// Bound by writing y (0.54 GB per 548 x 968 frame); as two launches the 64-channel input was also written and re-read as planes
+// and the weights went through conv_kernel's k loop for 4 k-steps per patch.  Here a wave takes 32 pixels: its lanes read their
+// pixel's 64 floats straight from the fp32 rows (kmap_first order: 32 contiguous bytes per k-step and lane half), one layer8
+// of 4 k-steps WITHOUT activation stages evaluates all 256 outputs, and the epilogue adds the bias, applies LeakyReLU and
+// stores.  The output rows are permuted in the packed weights so that register r of lane half h of row block IB is channel
+// 32 IB + 16 h + r: a lane owns the whole 16-channel chunk 2 IB + h of its pixel = 32 contiguous bytes of each plane.
+constexpr int HEAD_K = 64, HEAD_NS = HEAD_K / 16, HEAD_UNITS = HEAD_NS * 4, HEAD_SLOTS = HEAD_UNITS / UNITS_PER_SLOT;   // 16 units, 2 slots
+constexpr size_t HEAD_FRAGS = (size_t)HEAD_UNITS * 4 * 64;
+
+struct HeadParams {
+    const float *x;            // [H*W][64] fp32 rows
+    const half8 *wpk;
+    const float *bias;         // [256]
+    _Float16 *oh, *ol;         // output planes [16][Hb*Wb][16]
+    int32_t H, W, Wb;
+    long chunk_elems;          // Hb*Wb*16: element stride between channel chunks of a plane
+    int32_t tiles_per_row, n_tiles;
+};
+
+struct HeadPackParams {
+    const float *w1;           // [256, 64]
+    half8 *out;
+};
+
+__global__ __launch_bounds__(256) void head_pack_kernel(const HeadPackParams p) {
+    const int g = blockIdx.x * 256 + threadIdx.x;   // one thread per (unit, row block of the pair, lane)
+    if (g >= HEAD_UNITS * 2 * 64) return;
+    const int lane = g % 64, sel = (g / 64) % 2, u = g / 128;
+    int s, ib0;
+    unit_coords(8, HEAD_NS, u, s, ib0);
+    // MFMA row rho of the block = register (rho & 3) + 4 (rho >> 3) of lane half (rho >> 2) & 1  ->  channel 32 IB + 16 h + r
+    const int rho = lane & 31, ib = ib0 + sel;
+    const int row = 32 * ib + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+    const int h = lane >> 5;
+    half8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float v = p.w1[(size_t)row * HEAD_K + kmap_first(s, h, e)];
+        const _Float16 vh = (_Float16)v;
+        hi[e] = vh;
+        lo[e] = (_Float16)(v - (float)vh);
+    }
+    p.out[((size_t)u * 4 + 2 * sel + 0) * 64 + lane] = hi;
+    p.out[((size_t)u * 4 + 2 * sel + 1) * 64 + lane] = lo;
+}
+
+__global__ __launch_bounds__(256, 1) void head_kernel(const HeadParams p) {
+    constexpr int NOACT = 4;   // layer8's switch for "no activation stages" (the ablation bit): the epilogue below is the activation
+    __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    float *cst = reinterpret_cast<float *>(lds + LDS_CONST);
+    for (int i = threadIdx.x; i < HID; i += 256) cst[i] = p.bias[i];
+    __syncthreads();
+
+    Ring r;
+    r.slots_per_pass = HEAD_SLOTS;
+    r.wbytes = reinterpret_cast<const char *>(p.wpk);
+    r.g = 0;
+    r.wave = __builtin_amdgcn_readfirstlane(wave);
+    r.lane = lane;
+    r.voff = r.wave * (PIECES * 1024) + lane * 16;
+    r.lds_lane = (unsigned)(size_t)(const lds_char *)(lds + LDS_RING) + lane * 16;
+    r.src_delta = r.wave * (PIECES * 1024) - (int)(unsigned)(size_t)(const lds_char *)(lds + LDS_RING);
+#pragma unroll
+    for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, sl, sl % HEAD_SLOTS);   // (the stream of a pass is 2 slots: it wraps)
+    r.next_in_pass = DMA_AHEAD % HEAD_SLOTS;
+
+    const int n_groups = (p.n_tiles + 3) >> 2;
+    for (int grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const int tile = grp * 4 + wave;
+        const bool tile_ok = tile < p.n_tiles;
+        const int t = tile_ok ? tile : p.n_tiles - 1;
+        const int y = t / p.tiles_per_row, x = (t - y * p.tiles_per_row) * 32 + j;
+        const bool ok = tile_ok && x < p.W;
+        const int xc = x < p.W ? x : p.W - 1;
+        const float *src = p.x + ((size_t)y * p.W + xc) * HEAD_K + 8 * h;
+        half8 bh[16], bl[16];
+        f32x16 acc[8];
+#pragma unroll
+        for (int s = 0; s < HEAD_NS; s++) {
+            const float4 a = *reinterpret_cast<const float4 *>(src + 16 * s), b = *reinterpret_cast<const float4 *>(src + 16 * s + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            split8(v, bh[s], bl[s]);
+        }
+        float part = 0.f;
+        layer8<NOACT, HEAD_NS, false, false, false>(lds, r, bh, bl, acc, cst, cst, cst, h, part);
+        // ---- bias, LeakyReLU, f16 hi / lo split, stores: register r of row block ib is channel 32 ib + 16 h + r of this lane's pixel
+        const long pix = ((long)(y + 1) * p.Wb + (xc + 1)) * 16;
+#pragma unroll
+        for (int ib = 0; ib < 8; ib++) {
+            const float *bsrc = cst + 32 * ib + 16 * h;
+            half8 hv[2], lv[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const float4 b0 = *reinterpret_cast<const float4 *>(bsrc + 8 * q), b1 = *reinterpret_cast<const float4 *>(bsrc + 8 * q + 4);
+                const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const float t0 = acc[ib][8 * q + e] + bb[e];
+                    v[e] = vmax_raw(t0, 0.2f * t0);   // LeakyReLU(0.2), as conv_kernel's epilogue
+                }
+                split8(v, hv[q], lv[q]);
+            }
+            if (ok) {
+                _Float16 *oh = p.oh + (long)(2 * ib + h) * p.chunk_elems + pix, *ol = p.ol + (long)(2 * ib + h) * p.chunk_elems + pix;
+                *reinterpret_cast<half8 *>(oh) = hv[0];
+                *reinterpret_cast<half8 *>(oh + 8) = hv[1];
+                *reinterpret_cast<half8 *>(ol) = lv[0];
+                *reinterpret_cast<half8 *>(ol + 8) = lv[1];
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the ring runs DMA_AHEAD slots ahead: let it land before the LDS is released
+    __builtin_amdgcn_s_barrier();
+}
+
 }  // namespace
 
 // =====================================================================================================
@@ -2740,6 +2863,35 @@ int sdn_conv_chain(const void *in_hi, const void *in_lo, const void *packed, con
     if (wg > n_groups) wg = n_groups;
     hipLaunchKernelGGL(chain_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_conv_chain");
+}
+
+size_t sdn_conv_head_packed_weight_bytes(void) { return HEAD_FRAGS * sizeof(half8); }
+
+int sdn_conv_head_pack_weights(const float *w1, void *packed, sdn_stream_t stream) {
+    SDN_REQUIRE(w1 && packed, "sdn_conv_head_pack_weights: null pointer");
+    HeadPackParams p;
+    p.w1 = w1; p.out = (half8 *)packed;
+    hipLaunchKernelGGL(head_pack_kernel, dim3(sdn::div_up(HEAD_UNITS * 2 * 64, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_conv_head_pack_weights");
+}
+
+int sdn_conv_head(const float *x, const void *packed, const float *bias, void *out_hi, void *out_lo, int H, int W, int n_workgroups,
+                  sdn_stream_t stream) {
+    SDN_REQUIRE(x && packed && bias && out_hi && out_lo && H > 0 && W > 0, "sdn_conv_head: bad argument");
+    HeadParams p;
+    p.x = x; p.wpk = (const half8 *)packed; p.bias = bias; p.oh = (_Float16 *)out_hi; p.ol = (_Float16 *)out_lo;
+    p.H = H; p.W = W;
+    int Hb, Wb;
+    sdn_conv_plane_dims(H, W, &Hb, &Wb);
+    p.Wb = Wb;
+    p.chunk_elems = (long)Hb * Wb * 16;
+    p.tiles_per_row = sdn::div_up(W, 32);
+    p.n_tiles = p.tiles_per_row * H;
+    const int n_groups = sdn::div_up(p.n_tiles, 4);
+    int wg = n_workgroups > 0 ? n_workgroups : 256;
+    if (wg > n_groups) wg = n_groups;
+    hipLaunchKernelGGL(head_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_conv_head");
 }
 
 size_t sdn_sky_packed_weight_bytes(void) { return SKY_PACKED_FRAGS * sizeof(half8); }

@@ -150,6 +150,35 @@ def test_cnn_tail_as_one_chain_equals_the_three_launches(renderer):
         assert (one - ref).abs().max().item() < 2e-4
 
 
+def test_cnn_head_kernel_equals_planes_plus_conv1(renderer):
+    """net_out rows -> conv1 -> LeakyReLU -> y planes as ONE kernel (sdn_conv_head) against sdn_conv_planes_from_f32 + conv1 as a
+    conv_kernel launch: the same hi + lo planes to f32 rounding, nothing written outside the frame."""
+    from scenedreamer_amd import capi
+    from scenedreamer_amd.cnn import MfmaCNN
+    torch.manual_seed(2)
+    for hw in ((5, 31), (37, 53), (300, 520)):
+        x = (torch.rand(1, hw[0], hw[1], 64, device="cuda") * 2 - 1)
+        ys = []
+        for chain in (True, False):
+            cnn = MfmaCNN(renderer, 3, chain=chain)
+            buf = cnn._buffers(*hw)
+            for t in buf["a"] + buf["b"]:
+                t.zero_()
+            xs = x.reshape(-1, 64).contiguous()
+            if chain:
+                capi.check(capi.lib().sdn_conv_head(xs.data_ptr(), cnn.head_packed.data_ptr(), cnn.head_bias.data_ptr(),
+                                                    buf["a"][0].data_ptr(), buf["a"][1].data_ptr(), hw[0], hw[1], 0,
+                                                    capi.current_stream(renderer.dev)), "sdn_conv_head")
+            else:
+                capi.check(capi.lib().sdn_conv_planes_from_f32(xs.data_ptr(), 64, buf["b"][0].data_ptr(), buf["b"][1].data_ptr(),
+                                                               hw[0], hw[1], capi.current_stream(renderer.dev)), "planes")
+                cnn._conv(buf["b"], "conv1", hw[0], hw[1], bias=renderer.w["denoiser.conv1.bias"], dst=buf["a"])
+            ys.append(buf["a"][0].float() + buf["a"][1].float())
+        d = (ys[0] - ys[1]).abs().max().item()
+        print(f"CNN head kernel vs planes + conv1 {hw}: max abs diff of y {d:.2e} (max |y| {ys[1].abs().max().item():.2f})")
+        assert d < 2e-6 and (ys[0] == 0).sum() >= (ys[1] == 0).sum() - 16   # (the zero border / out-of-frame pixels stay zero)
+
+
 def test_cnn_precision_gate_is_measured_per_style(renderer, scene256):
     """cnn_terms3x3 = None ("auto"): the lossy 1-term 3x3 convolutions are used only when the first frame of the style shows
     them within CNN_AUTO_BOUND of the 3-term image; otherwise the 3-term kernels run.  A new style re-opens the gate."""

@@ -27,4 +27,11 @@ if cnn.chain:
                                                                   cnn.chain_consts.data_ptr(), img.data_ptr(), H, W, 0,
                                                                   capi.current_stream(dev)), "sdn_conv_chain"), 5)
     print(f"conv4a -> conv4b -> conv4 as one chain {t_ch:.3f} ms (as launches: {t_11 + t_4b:.3f} ms)")
+    xs = x.reshape(-1, 64).contiguous()
+    t_hd = _time_ms(lambda: capi.check(capi.lib().sdn_conv_head(xs.data_ptr(), cnn.head_packed.data_ptr(), cnn.head_bias.data_ptr(),
+                                                                buf["a"][0].data_ptr(), buf["a"][1].data_ptr(), H, W, 0,
+                                                                capi.current_stream(dev)), "sdn_conv_head"), 5)
+    t_pl = _time_ms(lambda: capi.check(capi.lib().sdn_conv_planes_from_f32(xs.data_ptr(), 64, buf["b"][0].data_ptr(), buf["b"][1].data_ptr(),
+                                                                           H, W, capi.current_stream(dev)), "planes"), 5)
+    print(f"head (rows -> conv1 -> planes) {t_hd:.3f} ms (as launches: planes {t_pl:.3f} + conv1 {t_1:.3f} ms)")
 print(f"cnn total {t_all:.3f} ms   one conv3x3 {t_conv:.3f} ms   dbg={os.environ.get('SDN_CONV_DBG','0')}")

@@ -20,7 +20,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = {"field.hip": ["-fno-slp-vectorize"], "cnn.hip": []}
 # (mlp_kernel<DBG, CT, FUSED>: ...Lb1E = field_kernel, the single-kernel field: no input prefetch, a[190:255] are ordinary registers)
-KERNELS = ("mlp_kernelILi0ELi3ELb0E", "mlp_kernelILi0ELi2ELb0E", "mlp_kernelILi0ELi6ELb0E", "mlp_kernelILi0ELi3ELb1E", "mlp_kernelILi0ELi6ELb1E", "sky_kernelILi0ELi0", "sky_kernelILi0ELi1", "chain_kernelENS_11ChainParamsE", "conv_kernelILi9ELi0ELi3ELi16E", "conv_kernelILi9ELi0ELi3ELi27E", "conv_kernelILi9ELi0ELi3ELi255E",
+KERNELS = ("mlp_kernelILi0ELi3ELb0E", "mlp_kernelILi0ELi2ELb0E", "mlp_kernelILi0ELi6ELb0E", "mlp_kernelILi0ELi3ELb1E", "mlp_kernelILi0ELi6ELb1E", "sky_kernelILi0ELi0", "sky_kernelILi0ELi1", "chain_kernelENS_11ChainParamsE", "head_kernelENS_10HeadParamsE", "conv_kernelILi9ELi0ELi3ELi16E", "conv_kernelILi9ELi0ELi3ELi27E", "conv_kernelILi9ELi0ELi3ELi255E",
            "conv_kernelILi9ELi0ELi1ELi0E", "conv_kernelILi9ELi0ELi1ELi16E", "conv_kernelILi9ELi0ELi1ELi27E", "conv_kernelILi9ELi0ELi1ELi255E",
            "conv_kernelILi1ELi0ELi3ELi16E", "conv_kernelILi1ELi0ELi3ELi255E")
 REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")

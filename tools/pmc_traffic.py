@@ -23,7 +23,7 @@ KERNELS = {"mlp_kernel": ("mlp_kernel", 2.0), "encode_kernel": ("encode_kernel",
            "conv_kernel<9, 0, 1, 27> (conv2b/3b)": ("conv_kernel<9, 0, 1, 27>", 2.0),
            "conv_kernel<1, 0, 3, 16> (conv1/conv4a)": ("conv_kernel<1, 0, 3, 16>", 2.0),
            "conv_kernel<1, 0, 3, 255> (conv4b + conv4)": ("conv_kernel<1, 0, 3, 255>", 2.0),
-           "chain_kernel (conv4a -> conv4b -> conv4)": ("chain_kernel", 2.0)}
+           "chain_kernel (conv4a -> conv4b -> conv4)": ("chain_kernel", 2.0), "head_kernel (rows -> conv1 -> planes)": ("head_kernel", 1.0)}
 
 
 def counters(path):

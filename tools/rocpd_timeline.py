@@ -10,7 +10,7 @@ import sys
 
 
 def short(n):
-    for k in ("mlp_kernel", "sky_kernel", "encode_kernel", "rvip_kernel", "worklist_kernel", "planes_kernel", "occupancy_kernel", "chain_kernel"):
+    for k in ("mlp_kernel", "sky_kernel", "encode_kernel", "rvip_kernel", "worklist_kernel", "planes_kernel", "occupancy_kernel", "chain_kernel", "head_kernel"):
         if k in n:
             return k
     if "conv_kernel" in n:
