@@ -45,6 +45,8 @@
 //                     registers -- a lane's 8 levels x 8 channels ARE its 8 B fragments, so nothing is exchanged -- while the
 //                     accumulator / fragment-ring registers are dead.  No feature buffer, no 10.8 GB HBM round trip.
 //   sky_kernel        the same machinery for SKYMLP on every ray of the padded frame + the frame mean.
+//   head_kernel       the render CNN's first layer on the same machinery: net_out rows -> conv1 -> LeakyReLU -> activation planes.
+//   chain_kernel      the render CNN's 1x1 tail (conv4a -> conv4b + residual -> conv4 -> tanh) as a register-resident per-pixel MLP.
 #include <hip/hip_fp16.h>
 
 #include <cstdlib>
@@ -160,6 +162,8 @@ constexpr int QUAD_XOR2 = 0x4E;    // quad_perm [2,3,0,1]: lane ^ 2
 constexpr int QUAD_UP1 = 0x90;     // quad_perm [0,0,1,2]: lane - 1 (lane 0 of the quad reads itself)
 constexpr int QUAD_UP2 = 0x44;     // quad_perm [0,1,0,1]: lane - 2 (lanes 0, 1 read themselves)
 constexpr int QUAD_LAST = 0xFF;    // quad_perm [3,3,3,3]: the quad's last lane
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;   // lane i of a row of 16 reads lane i ^ 7 (reversal inside each group of 8)
+constexpr int DPP_ROW_MIRROR = 0x140;        // lane i reads lane 15 - i
 
 // =====================================================================================================
 // collapse
@@ -2057,11 +2061,13 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
 #pragma unroll
             for (int rg = 0; rg < 16; rg++) {
                 float v = ray_ok ? col[ib][rg] : 0.f;
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
-                v += __shfl_xor(v, 16);      // sum over the 32 rays of this half-wave
+                // sum over the 32 rays of this half-wave: within a row of 16 lanes by DPP (quad, half-row mirror, row mirror: every
+                // lane ends up with the row's sum), ONE LDS exchange for the other row (five ds_bpermute per value before)
+                v += quad_dpp<QUAD_XOR1>(v);
+                v += quad_dpp<QUAD_XOR2>(v);
+                v += quad_dpp<DPP_ROW_HALF_MIRROR>(v);
+                v += quad_dpp<DPP_ROW_MIRROR>(v);
+                v += __shfl_xor(v, 16);
                 if ((rg >> 2) == q) fsum[ib][rg & 3] += v;
             }
     }
