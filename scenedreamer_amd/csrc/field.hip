@@ -1102,6 +1102,42 @@ struct ActPlan {
     }
 };
 
+// The deadlines the schedules above rest on, checked at compile time for both plans of a 16-k-step layer: every half fragment
+// of the pending group is finished before the unit that first multiplies with its fragment (16 + 2k for fragment 8 + k), no half
+// fragment of the own group starts before its fragment's last use (k-step T of the lower half: units 32 + 2T, 33 + 2T), each is
+// visited once per phase in consecutive units, fragments 0..3 are complete before unit 56 (where a layer feeding an MX layer
+// converts K block 0), and consecutive half fragments alternate between the two ActIn slots.
+template <bool SPREAD, int... Us>
+constexpr bool act_plan_ok(std::integer_sequence<int, Us...>) {
+    int first[2][16] = {}, last[2][16] = {}, visits[2][16] = {}, slot[2][16] = {};
+    for (int g = 0; g < 2; g++)
+        for (int k = 0; k < 16; k++) first[g][k] = last[g][k] = -1;
+    bool ok = true;
+    auto visit = [&](int U, bool pend, bool own, int j, int phase, int sl, bool starts) {
+        if (!pend && !own) return;
+        if (pend && own) ok = false;
+        const int g = own ? 1 : 0;
+        if (first[g][j] < 0) { first[g][j] = U; slot[g][j] = sl; if (!starts || phase == 2) ok = false; }
+        else if (U != last[g][j] + 1 || phase != 2 || starts || sl != slot[g][j]) ok = false;
+        last[g][j] = U;
+        visits[g][j]++;
+    };
+    (visit(Us, ActPlan<0, 16, true, false, false, Us, SPREAD>::PEND, ActPlan<0, 16, true, false, false, Us, SPREAD>::OWN,
+           ActPlan<0, 16, true, false, false, Us, SPREAD>::J, ActPlan<0, 16, true, false, false, Us, SPREAD>::PHASE,
+           ActPlan<0, 16, true, false, false, Us, SPREAD>::SLOT, ActPlan<0, 16, true, false, false, Us, SPREAD>::STARTS), ...);
+    for (int j = 0; j < 16; j++) {
+        const int k = j / 2;
+        if (visits[0][j] != (last[0][j] - first[0][j] + 1) || visits[1][j] != (last[1][j] - first[1][j] + 1)) ok = false;
+        if (first[0][j] < 0 || last[0][j] >= 16 + 2 * k) ok = false;                        // pending: fragment 8 + k ready in time
+        if (first[1][j] < 34 + 2 * k || last[1][j] > 63) ok = false;                        // own: fragment k free, done inside the layer
+        if (k < 4 && last[1][j] >= 56) ok = false;                                          // K block 0 complete before its conversion
+        if (j > 0 && (slot[0][j] == slot[0][j - 1] || slot[1][j] == slot[1][j - 1])) ok = false;
+    }
+    return ok && slot[1][0] != slot[0][15];
+}
+static_assert(act_plan_ok<false>(std::make_integer_sequence<int, 64>{}), "ActPlan: one half fragment per unit");
+static_assert(act_plan_ok<true>(std::make_integer_sequence<int, 64>{}), "ActPlan<SPREAD>: half-rate schedule");
+
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int U, bool SPREAD = false>
 __device__ __forceinline__ void layer8_fetch(const float *bias, const float *bias_pend, const float *wsig, int h, LayerState &st) {
     using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U, SPREAD>;
@@ -1428,6 +1464,23 @@ struct OutPlan {
     static constexpr int J = U == 0 ? 0 : U + 1;
     static constexpr int T = ACT ? 8 + J / 2 : 8, HS = ACT ? J % 2 : 0;
 };
+
+template <int... Us>
+constexpr bool out_plan_ok(std::integer_sequence<int, Us...>) {
+    int done[16] = {};   // unit in which half fragment j is activated (+1), 0 = never
+    bool ok = true;
+    auto visit = [&](int U, bool act, bool two, int j) {
+        if (!act) return;
+        if (done[j]) ok = false;
+        done[j] = U + 1;
+        if (two) { if (done[j + 1]) ok = false; done[j + 1] = U + 1; }
+    };
+    (visit(Us, OutPlan<0, Us>::ACT, OutPlan<0, Us>::TWO, OutPlan<0, Us>::J), ...);
+    for (int j = 0; j < 16; j++)
+        if (!done[j] || done[j] - 1 >= 8 + j / 2) ok = false;   // fragment 8 + j/2 is consumed by unit 8 + j/2
+    return ok;
+}
+static_assert(out_plan_ok(std::make_integer_sequence<int, 16>{}), "OutPlan: every half fragment is ready before its k-step");
 
 template <int DBG, int U>
 __device__ __forceinline__ void out_fetch(const float *bias_pend, int h, OutState &st) {
