@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SDN_ABI_VERSION 1
+#define SDN_ABI_VERSION 2
 
 typedef void *sdn_stream_t; /* hipStream_t */
 
@@ -225,14 +225,30 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
  * 32-ray group starts with its own sample placement and collapsed-table gathers, executed by the wave that then runs the
  * MLP on them, straight into its MFMA operand registers.  No feature / dist / label / rayflag buffers; net_out is the same
  * bits as the two-kernel sequence produces.  Arguments: those of sdn_field_encode (inputs) and of sdn_field_mlp (weights,
- * sky, outputs, schedule) with the same meaning; colour_terms 3 or 6. */
+ * sky, outputs, schedule) with the same meaning; colour_terms 3 or 6.
+ *   cam_ori_dev: NULL, or dev f32 [3] -- the camera origin read from device memory instead of cam_ori_host (which may then be
+ *     NULL): Generator._forward_perpix receives it as the device tensor cam_ori_t (scenedreamer.py:313, :354).
+ *   weights_out + depth_out (both or neither; term_eps must be 0): dev f32 [n_rays, num_samples], ZEROED by the caller -- the
+ *     `weights` (volum_rendering_relu(...) * !sky_only, scenedreamer.py:373-376) and `rand_depth` (:346-352) return values of
+ *     _forward_perpix, consumed by inference_givenstyle_depth (:812-817).  Samples of 32-ray groups without any hit are not
+ *     visited: they keep the caller's zeros, which is their value. */
 int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
                      int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale,
                      const void *packed, const float *consts, const float *sky_c, const float *sky_avg, float *net_out,
                      int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
-                     int32_t strat_division, int32_t *ticket, sdn_stream_t stream);
+                     int32_t strat_division, int32_t *ticket, const float *cam_ori_dev, float *weights_out, float *depth_out,
+                     sdn_stream_t stream);
+
+/* LightningMLP.forward as an op (imaginaire/model_utils/layers.py:92-126; the nn.Module boundary of SURVEY 8(b)) for N = 1:
+ *   x dev f32 [n_rows, 128] hash-grid features; label dev u8 [n_rows] = index of the one in each row of the one-hot mask `m`
+ *   (fc_m_a(m) is a row lookup then); packed / consts as for sdn_field_render (ModLinear's per-style W * alpha and beta folded:
+ *   layers.py:247-269 with N = 1); outputs sigma dev f32 [n_rows] (fc_sigma, :114) and c dev f32 [n_rows, 64] (fc_out_c, :124).
+ *   The same MFMA layer machinery and arithmetic (3-term f16 split; colour_terms 3 or 6) as the fused field kernel.
+ *   ticket: as for sdn_field_mlp (NULL = static schedule). */
+int sdn_render_mlp(const float *x, const uint8_t *label, const void *packed, const float *consts, float *sigma, float *c,
+                   int64_t n_rows, int32_t colour_terms, int32_t n_workgroups, int32_t *ticket, sdn_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Render CNN: the convolutions of RenderCNN (imaginaire/generators/gancraft_base.py:175-225, forward :202-225) on MFMA
@@ -276,14 +292,15 @@ int sdn_conv_head(const float *x, const void *packed, const float *bias, void *o
  * (imaginaire/generators/gancraft_base.py:219-225, tanh :603) -- the per-pixel 256 -> 256 -> 256 -> 3 chain evaluated
  * register-resident on the field MLP's layer machinery (3-term f16 split everywhere): the 256-channel activation is read
  * ONCE and never written.  Same result as  sdn_conv(conv4a) -> sdn_conv(conv4b, resid = y, proj = conv4)  to f32 rounding.
- *   in_hi / in_lo: y as f16 planes (the layout of sdn_conv);  out_img dev f32 [3][H*W]
+ *   in_hi / in_lo: y as f16 planes (the layout of sdn_conv);  out_img dev f32 [3][H*W];  out_raw: NULL or dev f32 [3][H*W], conv4's
+ *   output BEFORE tanh -- RenderCNN.forward's own return value (gancraft_base.py:221-225; _forward_global returns both, :598-603)
  *   packed: sdn_conv_chain_packed_weight_bytes() bytes from sdn_conv_chain_pack_weights (w4a, w4b dev f32 [256,256]; w4 dev f32 [3,256])
  *   consts dev f32 [sdn_conv_chain_consts_floats()]: conv4a.bias[256] | conv4b.bias[256] | conv4.bias padded with zeros to 64 */
 size_t sdn_conv_chain_packed_weight_bytes(void);
 size_t sdn_conv_chain_consts_floats(void);
 int sdn_conv_chain_pack_weights(const float *w4a, const float *w4b, const float *w4, void *packed, sdn_stream_t stream);
-int sdn_conv_chain(const void *in_hi, const void *in_lo, const void *packed, const float *consts, float *out_img, int H, int W,
-                   int n_workgroups, sdn_stream_t stream);
+int sdn_conv_chain(const void *in_hi, const void *in_lo, const void *packed, const float *consts, float *out_img, float *out_raw,
+                   int H, int W, int n_workgroups, sdn_stream_t stream);
 
 /* Sky MLP for every ray + per-feature sum over rays: SKYMLP.forward(positional_encoding(raydirs, 5, incl_orig), z)
  * (imaginaire/generators/gancraft_base.py:150-169; the frame mean of scenedreamer.py:592-598 = column sums of sky_partial / n_rays).
@@ -301,9 +318,11 @@ int sdn_sky_pack_weights(const float *w1, const float *const *wh4_host, const fl
 /* the same stream with the hidden layers fc2..fc5 laid out for hidden_terms = 6 (f16 Whi fragments + block-scaled fp6) */
 int sdn_sky_pack_weights_mx(const float *w1, const float *const *wh4_host, const float *wc, void *packed, sdn_stream_t stream);
 /* hidden_terms: products of fc2..fc5: 3 = the 3-term f16 split, 6 = Whi.Xhi in f16 + block-scaled fp6 corrections (packed from
- * sdn_sky_pack_weights_mx); fc1 and fc_out_c always use the 3-term split */
+ * sdn_sky_pack_weights_mx); fc1 and fc_out_c always use the 3-term split.
+ * encoded: 0 = `raydirs` dev f32 [n_rays,3], the positional encoding is evaluated inside the kernel; 1 = `raydirs` is SKYMLP.forward's
+ * own argument x, dev f32 [n_rays,33] rows the caller already encoded (voxlib.positional_encoding; hidden_terms must be 3) */
 int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_partial, int32_t n_rays,
-                int32_t n_workgroups, float *sky_avg, uint32_t *counter, int32_t hidden_terms, sdn_stream_t stream);
+                int32_t n_workgroups, float *sky_avg, uint32_t *counter, int32_t hidden_terms, int32_t encoded, sdn_stream_t stream);
 
 /* test hook: C[32,32] = A[32,16] * B[16,32] through the MFMA operand layouts field.hip relies on */
 int sdn_debug_mfma_probe(const float *A, const float *B, float *C, sdn_stream_t stream);

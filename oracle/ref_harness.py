@@ -63,6 +63,8 @@ def install(native="oracle"):
     native="ref":    they are the reference's OWN sources compiled for the host (oracle/_ref,
                      oracle/build_ref.py) -- the whole reference, Python and native, on the CPU.
     native="hip":    they are scenedreamer_amd's HIP-backed shims (needs a GPU).
+    native="hip-fast": the same with scenedreamer_amd.install_shims(fast=True): the generator's render networks and its
+                     _forward_perpix / _forward_global run on the fused kernels (scenedreamer_amd/dropin.py).
     """
     sys.dont_write_bytecode = True  # never write __pycache__ into /root/reference
     from . import oracle as O
@@ -84,9 +86,11 @@ def install(native="oracle"):
         if name not in sys.modules:
             sys.modules[name] = _stub(name)
 
-    if native == "hip":
+    if native in ("hip", "hip-fast"):
         import scenedreamer_amd
-        scenedreamer_amd.install_shims()
+        from scenedreamer_amd import dropin
+        dropin.uninstall_import_hook()
+        scenedreamer_amd.install_shims(fast=native == "hip-fast")
     elif native == "ref":
         from . import ref_native
         sys.modules["voxlib"] = ref_native.load("voxlib")

@@ -60,13 +60,14 @@ _SIGNATURES = {
                             ctypes.c_float, c_p, ctypes.c_int32, c_p, c_p, c_p, c_p]),
     "sdn_field_render": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, c_f, c_p, ctypes.c_int32, c_p,
-                               ctypes.c_int32, c_p, c_p]),
+                               ctypes.c_int32, c_p, c_p, c_p, c_p, c_p]),
+    "sdn_render_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, ctypes.c_int32, ctypes.c_int32, c_p, c_p]),
     "sdn_sky_packed_weight_bytes": (ctypes.c_size_t, []),
     "sdn_sky_consts_floats": (ctypes.c_size_t, []),
     "sdn_sky_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_sky_pack_weights_mx": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_sky_partial_rows": (ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
-    "sdn_sky_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p, ctypes.c_int32, c_p]),
+    "sdn_sky_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32, c_p, c_p, ctypes.c_int32, ctypes.c_int32, c_p]),
     "sdn_conv_plane_dims": (None, [c_i, c_i, c_p, c_p]),
     "sdn_conv_packed_weight_bytes": (ctypes.c_size_t, [c_i, c_i, c_i]),
     "sdn_conv_pack_weights": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),
@@ -78,7 +79,7 @@ _SIGNATURES = {
     "sdn_conv_chain_packed_weight_bytes": (ctypes.c_size_t, []),
     "sdn_conv_chain_consts_floats": (ctypes.c_size_t, []),
     "sdn_conv_chain_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
-    "sdn_conv_chain": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    "sdn_conv_chain": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     "sdn_debug_mfma_probe": (c_i, [c_p, c_p, c_p, c_p]),
 }
 # entry points added by later kernels register themselves here (name -> (restype, argtypes))
@@ -106,7 +107,7 @@ def lib():
                     fn = getattr(L, name)  # AttributeError if the symbol is not exported
                     fn.restype = res
                     fn.argtypes = args
-                if L.sdn_abi_version() != 1:
+                if L.sdn_abi_version() != 2:
                     raise ImportError("libsdnative ABI version mismatch")
                 _lib = L
     return _lib

@@ -98,8 +98,11 @@ class MfmaCNN:
                                            p(proj[0]) if proj else None, p(proj[1]) if proj else None, p(img),
                                            H, W, 0, capi.current_stream(self.R.dev)), "sdn_conv")
 
-    def __call__(self, net_out):
-        """net_out [1,H,W,64] -> image [1,3,H,W] (tanh)."""
+    def __call__(self, net_out, raw=None):
+        """net_out [1,H,W,64] -> image [1,3,H,W] (tanh).  raw: optional f32 [1,3,H,W] that receives conv4's output before the
+        tanh (RenderCNN.forward's own return value, gancraft_base.py:221-225; needs the chained tail)."""
+        if raw is not None and not self.chain:
+            raise ValueError("the pre-tanh output is produced by the chained tail (chain=True)")
         R, w = self.R, self.R.w
         _, H, W, _ = net_out.shape
         buf = self._buffers(H, W)
@@ -129,7 +132,8 @@ class MfmaCNN:
         if self.chain:
             with torch.cuda.device(R.dev):
                 capi.check(capi.lib().sdn_conv_chain(A[0].data_ptr(), A[1].data_ptr(), self.chain_packed.data_ptr(),
-                                                     self.chain_consts.data_ptr(), img.data_ptr(), H, W, 0,
+                                                     self.chain_consts.data_ptr(), img.data_ptr(),
+                                                     raw.data_ptr() if raw is not None else None, H, W, 0,
                                                      capi.current_stream(R.dev)), "sdn_conv_chain")
             return img
         self._conv(A, "conv4a", H, W, bias=bias("conv4a"), dst=B)

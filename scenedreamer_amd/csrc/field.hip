@@ -145,7 +145,21 @@ struct MlpParams {
                                // persistent workgroups draw their 32-ray groups from it instead of taking every
                                // gridDim.x-th one (a static share that is mostly sky leaves its workgroup idle at the end)
     EncParams enc;             // FUSED (field_kernel): the encode stage's inputs; feat / dist / label / rayflag are unused then
+    const float *cam_ori_dev;  // FUSED, optional dev f32 [3]: the camera origin read from device memory (overrides enc.ori): callers that hold
+                               // it as a device tensor (Generator._forward_perpix's cam_ori_t) need no device -> host copy per call
+    float *w_out;              // MODE_FUSED_AUX: [R][ns] volume-rendering weight of every sample (weights * !sky_only, scenedreamer.py:373-376)
+    float *depth_out;          // MODE_FUSED_AUX: [R][ns] sample depths (rand_depth after the NaN / inf -> 0 replacement, :350-352)
+    float *sigma_out;          // MODE_RAW: [R] density fc_sigma(f) of every row (LightningMLP.forward's first output)
 };
+
+// mlp_kernel's input / output modes
+constexpr int MODE_BUFFER = 0;      // features from encode_kernel's buffer
+constexpr int MODE_FUSED = 1;       // field_kernel: every pass encodes its own samples
+constexpr int MODE_FUSED_AUX = 2;   // field_kernel that also writes the per-sample weights and depths (Generator._forward_perpix's
+                                    // `weights` / `rand_depth` outputs, used by inference_givenstyle_depth, scenedreamer.py:812-817)
+constexpr int MODE_RAW = 3;         // LightningMLP.forward as an op (imaginaire/model_utils/layers.py:92-126): rows of 128 f32 features
+                                    // + a label per row in, (sigma, colour features) per row out; no sample placement, no compositing.
+                                    // Row (tile, ch, j) = tile * 256 + ch * 32 + j: `R` counts rows, nch = 8, a tile = 256 rows.
 
 // Exchanges inside a quad of lanes (the 4 samples of a ray in a pass) as DPP operands of the consuming VALU instruction:
 // __shfl_* compiles to ds_bpermute_b32, an LDS round trip per exchange (64 of them in the volume-rendering epilogue of a pass).
@@ -485,6 +499,7 @@ struct EncSample {
     bool oob, valid, gnd; // outside the grid / a real sample of a real ray / world x <= 1 (scenedreamer.py:380)
     float dist;           // new_dists * dists_scale (0 for padding samples)
     int label;            // reduced label of the box the sample falls into
+    float depth;          // rand_depth after the NaN / inf -> 0 replacement (only the AUX field kernel reads it)
 };
 
 __device__ __forceinline__ EncSample enc_place(const EncParams &p, const RayBoxes &rb, const float (&d)[3], int rl, int sidx, bool ray_ok) {
@@ -501,6 +516,7 @@ __device__ __forceinline__ EncSample enc_place(const EncParams &p, const RayBoxe
     e.x2 = normalise_coord(wz, p.delim[2]);
     e.oob = p.genc_oob || e.x0 < 0.f || e.x0 > 1.f || e.x1 < 0.f || e.x1 > 1.f || e.x2 < 0.f || e.x2 > 1.f;
     e.dist = e.valid ? pl.dist * p.dists_scale : 0.f;
+    e.depth = pl.depth;
     int id = rb.id[0];
 #pragma unroll
     for (int k = 1; k < MAXM; k++) {
@@ -1566,8 +1582,9 @@ __device__ __forceinline__ void seg_tick(char *lds, int idx, unsigned &tprev) {
 // CT = number of split terms of the colour layers fc_5 / fc_6 (3, or 2 = without the Whi.Xlo products)
 // FUSED = the encode stage runs inside this kernel (field_kernel): a pass's B fragments, distances and labels come from
 //         enc_place / enc_level instead of the feature buffer, the ray flags from the intersections themselves
-template <int DBG, int CT, bool FUSED = false>
+template <int DBG, int CT, int MODE = MODE_BUFFER>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
+    constexpr bool FUSED = MODE == MODE_FUSED || MODE == MODE_FUSED_AUX, AUX = MODE == MODE_FUSED_AUX, RAW = MODE == MODE_RAW;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
@@ -1588,6 +1605,9 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         if (threadIdx.x < p.enc.ns + 1) e_lin[threadIdx.x] = p.enc.lin[threadIdx.x];
         for (int i = threadIdx.x; i < 1024; i += 256) e_lut[i] = p.enc.lut[i];
         enc.scales = e_scales; enc.lin = e_lin; enc.lut = e_lut;
+        if (p.cam_ori_dev) {   // (uniform: three scalar loads)
+            enc.ori[0] = p.cam_ori_dev[0]; enc.ori[1] = p.cam_ori_dev[1]; enc.ori[2] = p.cam_ori_dev[2];
+        }
     }
     __syncthreads();
 
@@ -1654,7 +1674,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         if constexpr (FUSED) {
             flag = vox_cur != 0 ? (uint8_t)0 : (uint8_t)1;   // scenedreamer.py:337
             vox_nxt = first_vox(grp_next);
-        } else flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
+        } else if constexpr (RAW) flag = tile_ok ? (uint8_t)0 : (uint8_t)1;   // every tile holds at least one row
+        else flag = ray_ok ? p.rayflag[ray] : (uint8_t)1;
         bool gnd = false;                                  // FUSED: any sample of the ray at world x <= 1 (:380)
         int drawn = grp_next + (int)gridDim.x;            // the group after next: static stride, or ...
         if (p.ticket && threadIdx.x == 0) drawn = 2 * (int)gridDim.x + atomicAdd(p.ticket, 1);   // ... the next undrawn one
@@ -1691,8 +1712,22 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             const long tc_s = (long)(tile_ok_s ? tile_s : 0) * p.nch + ch;    // tc as a scalar
             int lab;
             float dist;
+            float smp_depth = 0.f;   // AUX: this lane's sample depth
             float raw[8][8];
-            if constexpr (FUSED) {
+            // RAW: this lane's row of the [R, 128] feature matrix (clamped: lanes past the end evaluate the last row, store nothing)
+            const long row = (long)(tile_ok ? tile : 0) * 256 + ch * 32 + j;
+            if constexpr (RAW) {
+                const long rc = row < p.R ? row : (long)p.R - 1;
+                lab = p.label[rc];
+                dist = 0.f;
+                const float *src = p.feat + rc * FEAT + 8 * h;   // kmap_first: k-step s, lane half h = features 16 s + 8 h .. + 7
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const float4 a = *reinterpret_cast<const float4 *>(src + 16 * s), b = *reinterpret_cast<const float4 *>(src + 16 * s + 4);
+                    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                    split8(v, bh[s], bl[s]);
+                }
+            } else if constexpr (FUSED) {
                 // ---- the encode stage of THIS pass, by this wave, into its own B-fragment registers (the accumulators, the
                 //      fragment ring and the fp6 state are dead here, so the gathers of several levels can be in flight).
                 //      The loads are ordinary ones: hipcc's own vmcnt waits also retire the ring DMAs issued before them
@@ -1704,6 +1739,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 gnd = gnd || es.gnd;
                 lab = es.label;
                 dist = es.dist;
+                if constexpr (AUX) smp_depth = es.depth;
                 const bool use_feat = !(flag & 1);
                 // 4 levels' gathers (64 x 16 B per lane) in flight at a time: two round trips per pass instead of eight
 #pragma unroll
@@ -1816,7 +1852,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     tn = (long)tile2 * p.nch;
                 }
                 pf_tc = -1;
-                if (!FUSED && has_next && !(DBG & 256)) {
+                if (MODE == MODE_BUFFER && has_next && !(DBG & 256)) {
                     pf_tc = tn;
                     const char *base = reinterpret_cast<const char *>(p.feat + ((size_t)tn * 8 * 64 + lane) * 8);
                     // k-steps 2k, 2k+1 (2048 B apart), two 16-B halves each -> a[190+16k : 205+16k]
@@ -1842,6 +1878,19 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             layer_out<DBG>(lds, r, bh, bl, acc, col, cst + C_BETA + 4 * HID, h, part);
             seg_tick<DBG>(lds, 7, t_seg);
             const float sigma = part + __shfl_xor(part, 32) + cst[C_BSIGMA];
+            if constexpr (RAW) {   // LightningMLP.forward's outputs for this lane's row: (sigma, c), layers.py:114, :124
+                if (tile_ok && row < p.R) {
+                    if (h == 0) p.sigma_out[row] = sigma;
+#pragma unroll
+                    for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; g4++)   // registers 4 g4 .. 4 g4 + 3 of row block ib = features 32 ib + 8 g4 + 4 h + e
+                            *reinterpret_cast<float4 *>(p.net_out + (size_t)row * OUTC + 32 * ib + 8 * g4 + 4 * h) =
+                                make_float4(col[ib][4 * g4], col[ib][4 * g4 + 1], col[ib][4 * g4 + 2], col[ib][4 * g4 + 3]);
+                }
+                n_done = ch + 1;
+                continue;
+            }
             // ---- volume rendering (mc_utils.py:154-161) over the 4 samples of each ray in this pass ---------------
             const float fe = fmaxf(sigma, 0.f) * dist;
             float incl = fe;
@@ -1855,6 +1904,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             const float wgt = (1.f - __expf(-fe)) * __expf(-excl);
             carry += quad_dpp<QUAD_LAST>(incl);
             tsum += wgt;
+            if constexpr (AUX) {   // Generator._forward_perpix's `weights` (scenedreamer.py:373-376) and `rand_depth` (:346-352)
+                const int sidx = ch * SAMP_PER_STEP + q;
+                if (h == 0 && ray_ok && sidx < p.ns) {
+                    p.w_out[(size_t)ray * p.ns + sidx] = (flag & 1) ? 0.f : wgt;
+                    p.depth_out[(size_t)ray * p.ns + sidx] = smp_depth;
+                }
+            }
 #pragma unroll
             for (int ib = 0; ib < 2; ib++)
 #pragma unroll
@@ -1890,6 +1946,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         if (p.passes && threadIdx.x == 0) p.passes[grp] = (uint8_t)n_done;   // passes this group went through (tests / bench)
 
         // ---- blend the sky, store ---------------------------------------------------------------------------------
+        if constexpr (!RAW) {
         tsum += quad_dpp<QUAD_XOR1>(tsum);
         tsum += quad_dpp<QUAD_XOR2>(tsum);
         if constexpr (FUSED) {   // nosky = the ray's last intersection is a voxel, or one of its samples lies at world x <= 1 (:335, :382)
@@ -1919,6 +1976,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 *reinterpret_cast<float4 *>(p.net_out + (size_t)ray * OUTC + f0) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
+        }   // !RAW
         grp = grp_next;
         grp_next = grp_next2;
         vox_cur = vox_nxt;
@@ -1961,7 +2019,7 @@ constexpr int SC_BC = SC_BIASH + 4 * 256;                     // [64]
 constexpr int SC_TOTAL = SC_BC + 64;
 
 struct SkyParams {
-    const float *raydirs;   // [R,3]
+    const float *raydirs;   // [R,3] ray directions, or (PRE) [R,33] rows that are already positional-encoded
     const half8 *wpk;
     const float *consts;    // SC_TOTAL floats
     float *sky_c;           // [R,64]
@@ -2026,7 +2084,8 @@ __device__ __forceinline__ float sky_pe(int k, float d0, float d1, float d2) {
 }
 
 // SMX: the four hidden layers fc2..fc5 as f16 Whi.Xhi + fp6 corrections (layer8x; nothing amplifies the sky features' error)
-template <int DBG, int SMX>
+// PRE: the input rows are SKYMLP.forward's own argument x [R,33] (the caller ran voxlib.positional_encoding, gancraft_base.py:150-157)
+template <int DBG, int SMX, bool PRE = false>
 __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2056,14 +2115,21 @@ __global__ __launch_bounds__(256, 1) void sky_kernel(const SkyParams p) {
         const int ray = tile * 32 + j;
         const bool ray_ok = tile < p.n_tiles && ray < p.R;
         const int rr = ray_ok ? ray : p.R - 1;
-        const float d0 = p.raydirs[(size_t)rr * 3], d1 = p.raydirs[(size_t)rr * 3 + 1], d2 = p.raydirs[(size_t)rr * 3 + 2];
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+        if constexpr (!PRE) {
+            d0 = p.raydirs[(size_t)rr * 3]; d1 = p.raydirs[(size_t)rr * 3 + 1]; d2 = p.raydirs[(size_t)rr * 3 + 2];
+        }
         half8 bh[16], bl[16];
         f32x16 acc[8];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) v[e] = sky_pe(16 * s + 8 * h + e, d0, d1, d2);
+            for (int e = 0; e < 8; e++) {
+                const int k = 16 * s + 8 * h + e;
+                if constexpr (PRE) v[e] = k < SKY_IN ? p.raydirs[(size_t)rr * SKY_IN + k] : 0.f;
+                else v[e] = sky_pe(k, d0, d1, d2);
+            }
             split8(v, bh[s], bl[s]);
         }
         float part = 0.f;
@@ -2206,6 +2272,7 @@ struct ChainParams {
     const half8 *wpk;          // conv4a | conv4b | conv4 (64 rows, 3 used) in the packed unit order
     const float *consts;       // CC_TOTAL floats: conv4a.bias | conv4b.bias | conv4.bias padded to 64
     float *img;                // [3][H*W]
+    float *raw;                // optional [3][H*W]: conv4's output before tanh (RenderCNN.forward's return value, gancraft_base.py:221-225)
     int32_t H, W, Wb;
     long chunk_bytes;          // Hb*Wb*32: byte stride between channel chunks of a plane
     int32_t tiles_per_row, n_tiles;   // 32-pixel runs of one image row
@@ -2477,6 +2544,10 @@ __global__ __launch_bounds__(256, 1) void chain_kernel(const ChainParams p) {
             const size_t o = (size_t)cur.y * p.W + cur.x;
 #pragma unroll
             for (int c = 0; c < 3; c++) p.img[(size_t)c * p.H * p.W + o] = tanhf(col[0][c]);
+            if (p.raw) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) p.raw[(size_t)c * p.H * p.W + o] = col[0][c];
+            }
         }
         cur.y = nxt.y; cur.x = nxt.x; cur.ok = nxt.ok;
 #pragma unroll
@@ -2802,6 +2873,7 @@ static int fill_mlp(MlpParams &p, const char *who, const void *packed, const flo
     if (!(term_eps >= 0.f && term_eps < 1.f)) return sdn::fail(SDN_ERR_INVALID, "%s: term_eps must be in [0, 1)", who);
     p.term_depth = term_eps > 0.f ? -logf(term_eps) : 0.f;
     p.passes = passes;
+    p.cam_ori_dev = nullptr; p.w_out = nullptr; p.depth_out = nullptr; p.sigma_out = nullptr;
     p.feat = nullptr; p.dist = nullptr; p.label = nullptr; p.rayflag = nullptr;
     p.wpk = (const half8 *)packed;
     p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
@@ -2870,8 +2942,13 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
                      const float *voxel_dims_host, const float *lin_dev, const float *u_dev, int32_t n_rays, int32_t max_blocks,
                      int32_t num_samples, float sample_depth, float dists_scale, const void *packed, const float *consts,
                      const float *sky_c, const float *sky_avg, float *net_out, int32_t colour_terms, float term_eps, uint8_t *passes,
-                     int32_t n_workgroups, const int32_t *window_host, int32_t strat_division, int32_t *ticket, sdn_stream_t stream) {
+                     int32_t n_workgroups, const int32_t *window_host, int32_t strat_division, int32_t *ticket, const float *cam_ori_dev,
+                     float *weights_out, float *depth_out, sdn_stream_t stream) {
     MlpParams p;
+    SDN_REQUIRE((weights_out == nullptr) == (depth_out == nullptr), "sdn_field_render: weights_out and depth_out go together");
+    SDN_REQUIRE(!(weights_out && term_eps > 0.f), "sdn_field_render: the per-sample outputs need term_eps = 0 (every pass must run)");
+    static const float zero3[3] = {0.f, 0.f, 0.f};
+    if (cam_ori_dev && !cam_ori_host) cam_ori_host = zero3;
     if (int rc = fill_mlp(p, "sdn_field_render", packed, consts, sky_c, net_out, n_rays, num_samples, colour_terms, term_eps, passes,
                           window_host, sky_avg, ticket))
         return rc;
@@ -2880,17 +2957,44 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
                           strat_division))
         return rc;
     p.enc.win = p.win;
+    p.cam_ori_dev = cam_ori_dev; p.w_out = weights_out; p.depth_out = depth_out;
     SDN_REQUIRE(colour_terms != 2, "sdn_field_render: colour_terms must be 3 or 6 (the 2-term profile exists for sdn_field_mlp only)");
     const int wg = mlp_workgroups(p, n_workgroups);
 #ifdef SDN_MLP_ABLATION
     if (const char *e = getenv("SDN_MLP_DBG")) {   // timing experiments only
-        if (atoi(e) == 512) { hipLaunchKernelGGL((mlp_kernel<512, 6, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); return sdn::check_launch("sdn_field_render"); }
-        if (atoi(e) == 515) { hipLaunchKernelGGL((mlp_kernel<512, 3, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); return sdn::check_launch("sdn_field_render"); }
+        if (atoi(e) == 512) { hipLaunchKernelGGL((mlp_kernel<512, 6, MODE_FUSED>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); return sdn::check_launch("sdn_field_render"); }
+        if (atoi(e) == 515) { hipLaunchKernelGGL((mlp_kernel<512, 3, MODE_FUSED>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); return sdn::check_launch("sdn_field_render"); }
     }
 #endif
-    if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((mlp_kernel<0, 3, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    if (weights_out) {
+        if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, MODE_FUSED_AUX>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((mlp_kernel<0, 3, MODE_FUSED_AUX>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, MODE_FUSED>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((mlp_kernel<0, 3, MODE_FUSED>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_render");
+}
+
+// LightningMLP.forward as an op (imaginaire/model_utils/layers.py:92-126, N = 1 so the ModLinear modulation is folded into
+// the packed weights / consts exactly as for sdn_field_render)
+int sdn_render_mlp(const float *x, const uint8_t *label, const void *packed, const float *consts, float *sigma, float *c,
+                   int64_t n_rows, int32_t colour_terms, int32_t n_workgroups, int32_t *ticket, sdn_stream_t stream) {
+    SDN_REQUIRE(x && label && packed && consts && sigma && c, "sdn_render_mlp: null pointer");
+    SDN_REQUIRE(n_rows > 0 && n_rows < ((int64_t)1 << 31), "sdn_render_mlp: n_rows must be in [1, 2^31)");
+    SDN_REQUIRE(colour_terms == 3 || colour_terms == 6, "sdn_render_mlp: colour_terms must be 3 or 6");
+    MlpParams p;
+    p.feat = x; p.dist = nullptr; p.label = label; p.rayflag = nullptr;
+    p.wpk = (const half8 *)packed; p.consts = consts; p.sky_c = nullptr; p.net_out = c;
+    p.R = (int32_t)n_rows; p.ns = 32; p.nch = 8;
+    p.n_tiles = (int32_t)((n_rows + 255) / 256);
+    p.term_depth = 0.f; p.passes = nullptr;
+    p.win.n_src = p.R; p.win.pitch = 0; p.win.first = 0; p.win.cols = 0; p.win.ray0 = 0;
+    p.sky_avg = nullptr; p.ticket = ticket;
+    p.cam_ori_dev = nullptr; p.w_out = nullptr; p.depth_out = nullptr; p.sigma_out = sigma;
+    p.enc = EncParams{};
+    const int wg = mlp_workgroups(p, n_workgroups);
+    if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, MODE_RAW>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((mlp_kernel<0, 3, MODE_RAW>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    return sdn::check_launch("sdn_render_mlp");
 }
 
 size_t sdn_conv_chain_packed_weight_bytes(void) { return CHAIN_FRAGS * sizeof(half8); }
@@ -2905,11 +3009,12 @@ int sdn_conv_chain_pack_weights(const float *w4a, const float *w4b, const float 
     return sdn::check_launch("sdn_conv_chain_pack_weights");
 }
 
-int sdn_conv_chain(const void *in_hi, const void *in_lo, const void *packed, const float *consts, float *out_img, int H, int W,
-                   int n_workgroups, sdn_stream_t stream) {
+int sdn_conv_chain(const void *in_hi, const void *in_lo, const void *packed, const float *consts, float *out_img, float *out_raw,
+                   int H, int W, int n_workgroups, sdn_stream_t stream) {
     SDN_REQUIRE(in_hi && in_lo && packed && consts && out_img && H > 0 && W > 0, "sdn_conv_chain: bad argument");
     ChainParams p;
     p.yh = (const _Float16 *)in_hi; p.yl = (const _Float16 *)in_lo; p.wpk = (const half8 *)packed; p.consts = consts; p.img = out_img;
+    p.raw = out_raw;
     p.H = H; p.W = W;
     int Hb, Wb;
     sdn_conv_plane_dims(H, W, &Hb, &Wb);
@@ -2991,7 +3096,7 @@ static int sky_workgroups(int32_t n_rays, int32_t n_workgroups) {
 int32_t sdn_sky_partial_rows(int32_t n_rays, int32_t n_workgroups) { return n_rays > 0 ? 4 * sky_workgroups(n_rays, n_workgroups) : 0; }
 
 int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, float *sky_c, float *sky_partial, int32_t n_rays,
-                int32_t n_workgroups, float *sky_avg, uint32_t *counter, int32_t hidden_terms, sdn_stream_t stream) {
+                int32_t n_workgroups, float *sky_avg, uint32_t *counter, int32_t hidden_terms, int32_t encoded, sdn_stream_t stream) {
     SDN_REQUIRE(raydirs && packed && consts && sky_c && sky_partial && n_rays > 0, "sdn_sky_mlp: bad argument");
     SDN_REQUIRE((sky_avg == nullptr) == (counter == nullptr), "sdn_sky_mlp: sky_avg and counter go together");
     SkyParams p;
@@ -3001,7 +3106,11 @@ int sdn_sky_mlp(const float *raydirs, const void *packed, const float *consts, f
     p.n_tiles = sdn::div_up(n_rays, 32);
     const int wg = sky_workgroups(n_rays, n_workgroups);
     SDN_REQUIRE(hidden_terms == 3 || hidden_terms == 6, "sdn_sky_mlp: hidden_terms must be 3 or 6");
-    if (hidden_terms == 6) hipLaunchKernelGGL((sky_kernel<0, 1>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    SDN_REQUIRE(encoded == 0 || encoded == 1, "sdn_sky_mlp: encoded must be 0 (ray directions) or 1 (positional-encoded rows)");
+    if (encoded) {
+        SDN_REQUIRE(hidden_terms == 3, "sdn_sky_mlp: positional-encoded input rows are evaluated with the 3-term split only");
+        hipLaunchKernelGGL((sky_kernel<0, 0, true>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
+    } else if (hidden_terms == 6) hipLaunchKernelGGL((sky_kernel<0, 1>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((sky_kernel<0, 0>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_sky_mlp");
 }

@@ -1,0 +1,383 @@
+"""The fused fast path behind the reference generator's OWN surface.
+
+`imaginaire.generators.scenedreamer.Generator.inference_givenstyle` (scenedreamer.py:479-632) calls, per frame and per tile,
+
+    voxlib.ray_voxel_intersection_perspective   -> shims/voxlib.py            (sdn_rvip)
+    voxlib.positional_encoding + self.sky_net   -> modules.SKYMLPNative       (sdn_sky_mlp)
+    self._forward_perpix(...)                   -> fast_forward_perpix below  (sdn_field_render: sample placement + hash
+                                                   grid + LightningMLP + volume rendering + sky compositing in ONE kernel)
+    self._forward_global(net_out, z)            -> fast_forward_global below  (cnn.MfmaCNN: the MFMA render CNN)
+
+With `scenedreamer_amd.install_shims(fast=True)` these bindings are put in place FROM OUTSIDE while the unmodified
+`imaginaire` package is imported (a sys.meta_path hook that post-processes three modules; the reference's files stay
+byte-identical), or -- for a generator that already exists -- by `accelerate(G)`.
+
+What the bound methods promise: for every call the reference's own method would serve, the same `net_out` / images within
+the float tolerance of the native kernels (1e-3 abs, tests/test_dropin_gpu.py).  Calls the fused kernel does not implement
+(autograd, batch > 1, box-boundary sampling, a view-direction input, ...) are handed to the reference's own method (kept as
+`_forward_perpix_reference` / `_forward_global_reference`), which then runs on the module-level drop-ins (modules.py) and
+the HIP ops -- never on a CPU path.  `binding(G).stats` counts which way every call went and why.
+
+_forward_perpix returns the reference's 12-tuple.  `net_out` is always there.  With `aux=False` (default: the inference
+loop and Generator.forward only read `net_out`) the other eleven are None; with `aux=True` new_dists, weights,
+total_weights_raw, rand_depth, sky_mask, sky_only_mask and new_idx are produced as well (what inference_givenstyle_depth
+reads, scenedreamer.py:812-817); net_out_s, net_out_c, skynet_out_c and nosky_mask never leave the fused kernel.
+"""
+import importlib
+import importlib.abc
+import importlib.util
+import sys
+import types
+
+import numpy as np
+import torch
+
+from . import fused, modules, ops
+from .renderer import fold_denoiser, fold_render_net
+
+PERPIX_OUTPUTS = ("net_out", "new_dists", "weights", "total_weights_raw", "rand_depth", "net_out_s", "net_out_c", "skynet_out_c",
+                  "nosky_mask", "sky_mask", "sky_only_mask", "new_idx")
+
+
+class GeneratorBinding:
+    def __init__(self, aux=False):
+        self.B = modules.Backend()
+        self.aux = bool(aux)
+        self.stats = {"perpix_fast": 0, "perpix_reference": 0, "global_fast": 0, "global_reference": 0, "tiles_in_place": 0,
+                      "tiles_copied": 0, "sky_reused": 0, "sky_evaluated": 0, "why": {}}
+        self._scene_key = None
+        self._lut_src = None
+
+    # ------------------------------------------------------------------ what the fused kernel implements
+    def why_not_perpix(self, G, voxel_id, depth2, raydirs, cam_ori_t, z, global_enc):
+        if not (isinstance(voxel_id, torch.Tensor) and voxel_id.is_cuda and voxel_id.dtype == torch.int32):
+            return "voxel_id is not a CUDA int32 tensor"
+        if not modules._cuda_f32(depth2, raydirs, cam_ori_t, z, global_enc):
+            return "inputs are not CUDA float32 tensors"
+        if modules._wants_grad(G.render_net, z, global_enc) or modules._wants_grad(G.hash_encoder):
+            return "autograd requested (the kernels are forward-only)"
+        if voxel_id.dim() != 5 or voxel_id.shape[0] != 1 or z.shape[0] != 1 or voxel_id.shape[-1] != 1:
+            return "batch size > 1"
+        if not (1 <= voxel_id.shape[3] <= 8):
+            return "more than 8 intersections per ray"
+        if G.sample_use_box_boundaries:
+            return "sample_use_box_boundaries"
+        if not (0 < G.num_samples <= 78):
+            return "more than 78 samples per ray"
+        if G.raw_noise_std > 0:
+            return "raw_noise_std > 0"
+        if not (G.keep_sky_out and G.keep_sky_out_avgpool and (hasattr(G, "sky_avg") or G.sky_global_avgpool)):
+            return "sky blending other than keep_sky_out_avgpool with a global average"
+        if G.clip_feat_map is not True:
+            return "clip_feat_map is not True"
+        if not (G.pe_params[2] == 0 and G.pe_params[3] is False):
+            return "view-direction input to the render MLP"
+        if list(G.pe_params_sky) != [5, True]:
+            return "sky positional encoding other than (5, incl_orig)"
+        he = G.hash_encoder
+        if not (getattr(he, "input_dim", 0) == 5 and getattr(he, "level_dim", 0) == 8 and getattr(he, "num_levels", 0) == 16 and
+                getattr(he, "gridtype", "") == "hash" and not getattr(he, "align_corners", True) and
+                he.embeddings.dtype == torch.float32):
+            return "hash grid other than 5-D / 16 levels / 8 channels / hashed"
+        why = _render_net_reason(G.render_net)
+        if why:
+            return "render_net: " + why
+        if tuple(G.sky_net.fc1.weight.shape) != (256, 33) or tuple(G.sky_net.fc_out_c.weight.shape) != (64, 256):
+            return "sky_net sizes"
+        return None
+
+    # ------------------------------------------------------------------ per-call state
+    def sync(self, G, z, global_enc):
+        """Bring the backend in line with the generator's live state; everything is cached on identities / version counters,
+        so a steady-state call costs a few tuple comparisons and no device synchronisation."""
+        B = self.B
+        B.bind("render_net.", G.render_net)
+        B.bind("sky_net.", G.sky_net)
+        grid_changed = B.bind("hash_encoder.", G.hash_encoder)
+        B.M = int(G.num_blocks_early_stop)
+        B.sample_depth, B.dists_scale = float(G.sample_depth), float(G.dists_scale)
+        he = G.hash_encoder
+        B.grid_L = int(he.num_levels)
+        B.grid_S = float(np.log2(he.per_level_scale))
+        vt = G.voxel.voxel_t
+        skey = (vt.data_ptr(), vt._version, tuple(vt.shape), global_enc.data_ptr(), global_enc._version)
+        if grid_changed or skey != self._scene_key:
+            lt = G.label_trans
+            lut = lt.mcid2rdid_lut.clone()
+            lut[lut == lt.ignore_id] = lt.dirt_id                    # mc2reduced(ign2dirt=True), mc_utils.py:241-246
+            B.lut = lut.to(B.dev)
+            B.voxel_dims = tuple(int(v) for v in vt.shape)
+            B.max_block_id = int(vt.max()) if vt.numel() else 0      # (one synchronisation per scene)
+            B.global_enc = global_enc.detach().reshape(1, 2)
+            B._fused_scene = None
+            self._scene_key = skey
+        B.style("render_net.", z, 0, fold_render_net)
+        B.style("sky_net.", z, 0, modules.fold_sky_net)
+
+    # ------------------------------------------------------------------ rays of the call
+    @staticmethod
+    def frame_window(voxel_id, depth2, raydirs):
+        """If the three arguments are views of contiguous frame-wide arrays voxel_id_all [1,H0,W0,M,1], depth2_all
+        [1,2,H0,W0,M,1], raydirs_all [1,H0,W0,1,3] cut to the same tile -- how inference_givenstyle produces them,
+        scenedreamer.py:600-616 -- return (Window, base addresses): the kernel then reads the frame-wide arrays in place."""
+        _, h, w, M, _ = voxel_id.shape
+        if tuple(depth2.shape) != (1, 2, h, w, M, 1) or tuple(raydirs.shape) != (1, h, w, 1, 3) or h == 0 or w == 0:
+            return None
+        sv, sd, sr = voxel_id.stride(), depth2.stride(), raydirs.stride()
+        # (strides of size-1 dimensions are arbitrary: a constraint is only read off a dimension that has more than one entry)
+        if (M > 1 and (sv[3] != 1 or sd[4] != 1)) or sr[4] != 1:
+            return None
+        if w > 1 and (sv[2] != M or sd[3] != M or sr[2] != 3):
+            return None
+        if sd[1] % M:
+            return None
+        n_src = sd[1] // M                                   # rays per plane of depth2_all = rays of the frame
+        if h > 1:
+            if sv[1] % M or sd[2] != sv[1] or sr[1] * M != sv[1] * 3:
+                return None
+            pitch = sv[1] // M
+        else:
+            pitch = w
+        ov, od, orr = voxel_id.storage_offset(), depth2.storage_offset(), raydirs.storage_offset()
+        if ov % M or od != ov or orr * M != ov * 3:          # the same tile of all three frames
+            return None
+        first = ov // M
+        if pitch < w or first + (h - 1) * pitch + w > n_src:
+            return None
+        # the frame-wide arrays must lie inside the storages the views belong to
+        if (voxel_id.untyped_storage().nbytes() < n_src * M * 4 or depth2.untyped_storage().nbytes() < 2 * n_src * M * 4 or
+                raydirs.untyped_storage().nbytes() < n_src * 3 * 4):
+            return None
+        bases = (voxel_id.data_ptr() - ov * 4, depth2.data_ptr() - od * 4, raydirs.data_ptr() - orr * 4)
+        return fused.Window(n_src, pitch, first, h, w), bases
+
+    def rays(self, G, voxel_id, depth2, raydirs):
+        """(window, voxel_id, depth2, raydirs, sky_c) for sdn_field_render: frame-wide arrays read in place through a window when
+        the sky features of the whole frame are at hand (SKYMLPNative keeps those of the pre-pass), else tile-local copies."""
+        B = self.B
+        _, h, w, M, _ = voxel_id.shape
+        last = G.sky_net.__dict__.get("_sdn_last_frame") if modules.is_native(G.sky_net) else None
+        fw = self.frame_window(voxel_id, depth2, raydirs) if last is not None else None
+        if fw is not None:
+            win, (pv, pd, pr) = fw
+            if (last["rd_ptr"] == pr and last["n_rays"] == win.n_src and last["rd_version"] == raydirs._version and
+                    last["zkey"] is not None and last["zkey"] == B._zkey.get("sky_net.") and
+                    last["wkey"] == modules.Backend.tensors_key(G.sky_net)):
+                self.stats["tiles_in_place"] += 1
+                self.stats["sky_reused"] += 1
+                return win, pv, pd, pr, last["sky_c"], None
+        n = h * w
+        vid = voxel_id.reshape(n, M).contiguous()
+        d2 = depth2.reshape(2, n, M).contiguous()
+        rd = raydirs.reshape(n, 3).contiguous()
+        sky_c, sky_mean = fused.sky_fused(B, rd)
+        self.stats["tiles_copied"] += 1
+        self.stats["sky_evaluated"] += 1
+        return fused.Window(n), vid, d2, rd, sky_c, sky_mean
+
+
+def _render_net_reason(net):
+    """Why the fused kernel cannot stand in for this LightningMLP (None: it can) -- the size / structure part of
+    modules.LightningMLPNative.native_reason, for the reference's plain class as well."""
+    try:
+        if net.fc_viewdir is not None:
+            return "viewdir_dim > 0"
+        if not (tuple(net.fc_1.weight.shape) == (256, 128) and tuple(net.fc_out_c.weight.shape) == (64, 256) and
+                net.fc_sigma.weight.shape[0] == 1 and (not net.use_seg or net.fc_m_a.weight.shape[1] == 12)):
+            return "layer sizes other than 128 -> 256 x6 -> 1 + 64 with 12 labels"
+        for i in (2, 3, 4, 5, 6):
+            f = getattr(net, f"fc_{i}")
+            if not (f.output_mode and f.mod_bias and f.bias is None):
+                return f"fc_{i} is not a bias-free output-mode ModLinear"
+    except AttributeError as e:
+        return f"not a LightningMLP ({e})"
+    return None
+
+
+def binding(G, aux=None):
+    b = G.__dict__.get("_sdn_binding")
+    if b is None:
+        b = G.__dict__["_sdn_binding"] = GeneratorBinding()
+    if aux is not None:
+        b.aux = bool(aux)
+    return b
+
+
+def _count(b, key, why=None):
+    b.stats[key] += 1
+    if why:
+        b.stats["why"][why] = b.stats["why"].get(why, 0) + 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the two methods
+# ---------------------------------------------------------------------------------------------------------------------
+def fast_forward_perpix(self, blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z, global_enc):
+    """Generator._forward_perpix (scenedreamer.py:313-430) on sdn_field_render.  Same arguments; returns the same 12-tuple
+    (see the module docstring for which entries are filled)."""
+    b = binding(self)
+    why = b.why_not_perpix(self, voxel_id, depth2, raydirs, cam_ori_t, z, global_enc)
+    if why is not None:
+        _count(b, "perpix_reference", why)
+        return self._forward_perpix_reference(blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z, global_enc)
+    _count(b, "perpix_fast")
+    B = b.B
+    with torch.no_grad():
+        b.sync(self, z, global_enc)
+        _, h, w, M, _ = voxel_id.shape
+        ns = int(self.num_samples)
+        win, vid, d2, rd, sky_c, sky_mean = b.rays(self, voxel_id, depth2, raydirs)
+        if hasattr(self, "sky_avg"):                          # the frame-wide pre-pass of inference_givenstyle, :592-598
+            sky_avg = self.sky_avg
+        else:                                                 # sky_global_avgpool over the rays of this call, :392-393
+            sky_avg = sky_mean if sky_mean is not None else sky_c.mean(dim=0)
+        u = None
+        if not self.coarse_deterministic_sampling:            # the reference's draw, mc_utils.py:121 (nsamples = num_samples + 1)
+            u = torch.rand([1, h, w, ns + 1, 1], dtype=depth2.dtype, device=depth2.device).reshape(h * w, ns + 1)
+        aux = {} if b.aux else None
+        if aux is not None and fused.precision_profile(B)[1] > 0:
+            raise RuntimeError("aux outputs need early ray termination off (term_eps = 0)")
+        net_out = fused.field_render(B, vid, d2, rd, cam_ori_t, sky_c, sky_avg, ns, u=u, window=win, aux=aux)
+        out = [None] * len(PERPIX_OUTPUTS)
+        out[0] = net_out.view(1, h, w, 64)
+        if aux is not None:
+            # the same values the reference returns (scenedreamer.py:335-352, :373-377); samples come from the stand-alone op
+            rand_depth, new_dists, new_idx = ops.sample_depth_batched(
+                depth2, ns + 1, deterministic=u is None, use_box_boundaries=False, sample_depth=self.sample_depth,
+                rand=u.view(1, h, w, ns + 1, 1) if u is not None else None)
+            rand_depth = torch.where(torch.isnan(rand_depth) | torch.isinf(rand_depth), torch.zeros_like(rand_depth), rand_depth)
+            weights = aux["weights"].view(1, h, w, ns, 1)
+            out[1], out[2], out[3], out[4] = new_dists, weights, weights.sum(dim=-2, keepdim=True), rand_depth
+            out[9] = voxel_id[:, :, :, [-1], :] == 0
+            out[10] = voxel_id[:, :, :, [0], :] == 0
+            out[11] = new_idx
+    return tuple(out)
+
+
+def fast_forward_global(self, net_out, z):
+    """Base3DGenerator._forward_global (gancraft_base.py:588-603) on the MFMA render CNN: net_out [1,H,W,64] -> (tanh image,
+    conv4 output) [1,3,H,W] each."""
+    b = binding(self)
+    den = self.denoiser
+    why = None
+    if not modules._cuda_f32(net_out, z):
+        why = "inputs are not CUDA float32 tensors"
+    elif modules._wants_grad(den, net_out, z):
+        why = "autograd requested (the kernels are forward-only)"
+    elif net_out.dim() != 4 or net_out.shape[0] != 1 or net_out.shape[-1] != 64 or z.shape[0] != 1:
+        why = "batch size > 1 or a feature width other than 64"
+    elif tuple(den.conv1.weight.shape) != (256, 64, 1, 1):
+        why = "denoiser sizes"
+    if why is not None:
+        _count(b, "global_reference", why)
+        return self._forward_global_reference(net_out, z)
+    _count(b, "global_fast")
+    B = b.B
+    with torch.no_grad():
+        B.bind("denoiser.", den)
+        B.style("denoiser.", z, 0, fold_denoiser)
+        x = net_out.contiguous()
+        raw = torch.empty((1, 3, x.shape[1], x.shape[2]), dtype=torch.float32, device=x.device)
+        img = B.mfma_cnn(x)(x, raw=raw)
+    return img, raw
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# installation
+# ---------------------------------------------------------------------------------------------------------------------
+def accelerate(G, aux=False):
+    """Bind the fast path to an existing reference generator: the classes of its render_net / sky_net / denoiser get the
+    native forwards (parameters untouched), its _forward_perpix / _forward_global become the methods above."""
+    for name in ("render_net", "sky_net", "denoiser"):
+        modules.make_fast(type(getattr(G, name)))
+    cls = type(G)
+    if "_forward_perpix_reference" not in G.__dict__ and not hasattr(cls, "_forward_perpix_reference"):
+        G._forward_perpix_reference = types.MethodType(cls._forward_perpix, G)
+        G._forward_global_reference = types.MethodType(cls._forward_global, G)
+        G._forward_perpix = types.MethodType(fast_forward_perpix, G)
+        G._forward_global = types.MethodType(fast_forward_global, G)
+    binding(G, aux=aux)
+    return G
+
+
+def _patch_layers(mod):
+    mod.LightningMLP = modules.make_fast(mod.LightningMLP)
+
+
+def _patch_base(mod):
+    mod.SKYMLP = modules.make_fast(mod.SKYMLP)
+    mod.RenderCNN = modules.make_fast(mod.RenderCNN)
+
+
+def _patch_generator(mod):
+    G = mod.Generator
+    if "_forward_perpix_reference" not in G.__dict__:
+        G._forward_perpix_reference = G._forward_perpix
+        G._forward_global_reference = G._forward_global
+        G._forward_perpix = fast_forward_perpix
+        G._forward_global = fast_forward_global
+
+
+_TARGETS = {"imaginaire.model_utils.layers": _patch_layers, "imaginaire.generators.gancraft_base": _patch_base,
+            "imaginaire.generators.scenedreamer": _patch_generator}
+
+
+class _PatchingLoader(importlib.abc.Loader):
+    def __init__(self, inner, patch):
+        self.inner, self.patch = inner, patch
+
+    def create_module(self, spec):
+        return self.inner.create_module(spec)
+
+    def exec_module(self, module):
+        self.inner.exec_module(module)
+        self.patch(module)
+
+    def __getattr__(self, name):          # get_code / get_source / is_package ...: the real loader answers
+        return getattr(self.inner, name)
+
+
+class _Finder(importlib.abc.MetaPathFinder):
+    """Post-processes the three modules of _TARGETS right after the import system has executed them: the reference's
+    source files are read and executed unchanged; only names in the finished module objects are rebound."""
+    def find_spec(self, name, path, target=None):
+        if name not in _TARGETS:
+            return None
+        spec = None
+        for finder in sys.meta_path:                      # whoever would have found the module without this hook
+            if finder is self or not hasattr(finder, "find_spec"):
+                continue
+            spec = finder.find_spec(name, path, target)
+            if spec is not None:
+                break
+        if spec is None or spec.loader is None:
+            return None
+        spec.loader = _PatchingLoader(spec.loader, _TARGETS[name])
+        return spec
+
+
+_finder = None
+
+
+def install_import_hook():
+    """Arrange for the reference's classes to come out of `import imaginaire...` with the native forwards (idempotent).
+    Modules that were imported before the hook are patched in place."""
+    global _finder
+    if _finder is None:
+        _finder = _Finder()
+        sys.meta_path.insert(0, _finder)
+    for name, patch in _TARGETS.items():
+        if name in sys.modules:
+            patch(sys.modules[name])
+    # `from imaginaire.model_utils.layers import LightningMLP` in an already imported scenedreamer module bound the old class
+    sd, ly = sys.modules.get("imaginaire.generators.scenedreamer"), sys.modules.get("imaginaire.model_utils.layers")
+    if sd is not None and ly is not None:
+        sd.LightningMLP = ly.LightningMLP
+
+
+def uninstall_import_hook():
+    global _finder
+    if _finder is not None:
+        if _finder in sys.meta_path:
+            sys.meta_path.remove(_finder)
+        _finder = None

@@ -212,10 +212,14 @@ SINGLE_KERNEL_DEFAULT = "1"   # same frame time as the two-kernel sequence (A/B,
 
 
 def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None, window=None, division="reciprocal",
-                 net_out=None):
+                 net_out=None, aux=None):
     """The whole field of a ray set in one launch (csrc/field.hip field_kernel): sample placement + hash-grid lookup + render
     MLP + compositing.  Same arguments and the same bits as field_fused's encode -> mlp sequence; no feature buffer, so no
-    ray chunking at any frame size."""
+    ray chunking at any frame size.
+    vid / d2 / rd / sky_c: tensors, or -- with a `window` -- plain device addresses (int) of frame-wide arrays of window.n_src
+    rays (Generator._forward_perpix's tile views of the per-frame voxlib outputs are evaluated in place that way).
+    cam_ori: host values, or a CUDA tensor -- then the kernel reads it from device memory (no device -> host copy).
+    aux: None, or a dict that receives "weights" and "depth" [n_rays, ns] (_forward_perpix's `weights` / `rand_depth`)."""
     sc = R._fused_scene or prepare_scene(R)
     st = R._fused_style or prepare_style(R)
     ct, eps = precision_profile(R)
@@ -224,10 +228,18 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
     if window is None:
         window = Window(vid.shape[0])
     n_rays = window.n_rays
-    assert vid.is_contiguous() and d2.is_contiguous() and rd.is_contiguous() and vid.shape[0] == window.n_src
-    sky_c = sky_c.contiguous()
+
+    def addr(t, rows, what):
+        if isinstance(t, int):
+            return t
+        assert t.is_cuda and t.device == R.dev and t.is_contiguous() and t.shape[rows] == window.n_src, what
+        return t.data_ptr()
+
+    if not isinstance(sky_c, int):
+        sky_c = sky_c.contiguous()
+    p_vid, p_d2, p_rd, p_sky = addr(vid, 0, "voxel_id"), addr(d2, 1, "depth2"), addr(rd, 0, "raydirs"), addr(sky_c, 0, "sky_c")
     sky_avg = torch.as_tensor(sky_avg).reshape(-1).to(device=R.dev, dtype=torch.float32).contiguous()
-    assert sky_avg.numel() == 64 and sky_c.is_cuda and sky_c.device == R.dev and sky_c.shape[0] == window.n_src
+    assert sky_avg.numel() == 64
     if net_out is None:
         net_out = torch.empty((n_rays, 64), dtype=torch.float32, device=R.dev)
     buf = R.__dict__.setdefault("_fused_lin", {})
@@ -242,15 +254,31 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
             lin = buf[("strat", ns)] = torch.linspace(0, 1, ns + 2)[:-1].contiguous().to(R.dev)      # mc_utils.py:124
     if "ticket" not in st:
         st["ticket"] = torch.zeros(2, dtype=torch.int32, device=R.dev)      # the kernel leaves it at zero
-    ori = np.asarray(cam_ori.detach().cpu().numpy() if isinstance(cam_ori, torch.Tensor) else cam_ori, np.float32)
+    ori_dev = None
+    if isinstance(cam_ori, torch.Tensor) and cam_ori.is_cuda:
+        ori_dev = cam_ori.detach().reshape(-1).to(torch.float32).contiguous()
+        assert ori_dev.numel() == 3 and ori_dev.device == R.dev
+        ori = np.zeros(3, np.float32)
+    else:
+        ori = np.asarray(cam_ori.detach().cpu().numpy() if isinstance(cam_ori, torch.Tensor) else cam_ori, np.float32).reshape(3)
+    w_out = d_out = None
+    if aux is not None:
+        if eps > 0:
+            raise ValueError("the per-sample outputs need term_eps = 0")
+        w_out = torch.zeros((n_rays, ns), dtype=torch.float32, device=R.dev)      # groups without a hit are not visited
+        d_out = torch.zeros((n_rays, ns), dtype=torch.float32, device=R.dev)
+        aux["weights"], aux["depth"] = w_out, d_out
     with torch.cuda.device(R.dev):
-        rc = _lib().sdn_field_render(vid.data_ptr(), d2.data_ptr(), rd.data_ptr(), sc["lut"].data_ptr(), sc["table3"].data_ptr(),
+        rc = _lib().sdn_field_render(p_vid, p_d2, p_rd, sc["lut"].data_ptr(), sc["table3"].data_ptr(),
                                      sc["T"], sc["scales"].data_ptr(), sc["genc"].ctypes.data, ori.ctypes.data,
                                      sc["dims"].ctypes.data, lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M,
                                      ns, R.sample_depth, R.dists_scale, st["packed_mx" if ct == 6 else "packed"].data_ptr(),
-                                     st["consts"].data_ptr(), sky_c.data_ptr(), sky_avg.data_ptr(), net_out.data_ptr(), ct, eps,
+                                     st["consts"].data_ptr(), p_sky, sky_avg.data_ptr(), net_out.data_ptr(), ct, eps,
                                      passes.data_ptr() if passes is not None else None, 0, window.host(0),
-                                     {"reciprocal": 0, "ieee": 1}[division], st["ticket"].data_ptr(), _stream(R.dev))
+                                     {"reciprocal": 0, "ieee": 1}[division], st["ticket"].data_ptr(),
+                                     ori_dev.data_ptr() if ori_dev is not None else None,
+                                     w_out.data_ptr() if w_out is not None else None, d_out.data_ptr() if d_out is not None else None,
+                                     _stream(R.dev))
     capi.check(rc, "sdn_field_render")
     return net_out
 
@@ -341,12 +369,14 @@ def prepare_sky(R):
     return R._fused_sky
 
 
-def sky_fused(R, rd):
+def sky_fused(R, rd, encoded=False):
     """sky_c [R,64] and the frame mean sky_avg [1,64] for ray directions rd [R,3] (the mean is finished inside the kernel by
-    its last workgroup: fixed summation order, no host-side reduction)."""
+    its last workgroup: fixed summation order, no host-side reduction).
+    encoded: rd is [R,33], rows that are already positional-encoded (SKYMLP.forward's own argument)."""
     sk = getattr(R, "_fused_sky", None) or prepare_sky(R)
     rd = rd.contiguous()
     n = rd.shape[0]
+    assert rd.dim() == 2 and rd.shape[1] == (33 if encoded else 3) and rd.dtype == torch.float32 and rd.device == R.dev
     sky_c = torch.empty((n, 64), dtype=torch.float32, device=R.dev)
     part = torch.empty((_lib().sdn_sky_partial_rows(n, 0), 64), dtype=torch.float32, device=R.dev)
     sky_avg = torch.empty((1, 64), dtype=torch.float32, device=R.dev)
@@ -354,9 +384,9 @@ def sky_fused(R, rd):
         sk["counter"] = torch.zeros(1, dtype=torch.int32, device=R.dev)     # the kernel leaves it at zero
     # hidden layers fc2..fc5: 3 = 3-term f16 split (default); 6 = f16 + fp6 corrections: 1.02 -> 0.87 ms per frame, but all
     # four hidden layers stack their ~2^-17 errors (1.1e-4 max on sky_c against 4.5e-6): opt-in
-    terms = getattr(R, "sky_terms", None) or int(os.environ.get("SDN_SKY_TERMS", "3"))
+    terms = 3 if encoded else (getattr(R, "sky_terms", None) or int(os.environ.get("SDN_SKY_TERMS", "3")))
     with torch.cuda.device(R.dev):
         capi.check(_lib().sdn_sky_mlp(rd.data_ptr(), sk["packed_mx" if terms == 6 else "packed"].data_ptr(), sk["consts"].data_ptr(),
                                       sky_c.data_ptr(), part.data_ptr(), n, 0, sky_avg.data_ptr(), sk["counter"].data_ptr(),
-                                      terms, _stream(R.dev)), "sdn_sky_mlp")
+                                      terms, 1 if encoded else 0, _stream(R.dev)), "sdn_sky_mlp")
     return sky_c, sky_avg

@@ -148,7 +148,8 @@ def _sample_depth_with_boundaries(depth2, nsamples, deterministic, sample_depth,
     N, _, H, W, M, _ = depth2.shape
     dev = depth2.device
     t, t2 = depth2[:, 0], depth2[:, 1]
-    d = torch.nan_to_num(t2 - t, nan=0.0)
+    d = t2 - t
+    d = torch.where(torch.isnan(d), torch.zeros_like(d), d)      # only NaNs are zeroed (mc_utils.py:101), infinities stay
     accu = torch.cumsum(d, dim=-2)
     total = accu[..., -1:, :].clamp(max=sample_depth)
     if boundary_rand is None:
@@ -199,6 +200,9 @@ def positional_encoding(in_feature, ndegrees, dim, incl_orig):
         rc = capi.lib().sdn_posenc_fwd(in_feature.data_ptr(), out.data_ptr(), pre, post, int(ndegrees),
                                        int(bool(incl_orig)), _stream(in_feature))
     capi.check(rc, "sdn_posenc_fwd")
+    # provenance for modules.SKYMLPNative: a consumer that is handed THIS tensor object, unmodified, may evaluate the encoding
+    # of `in_feature` itself (the sky kernel does) instead of reading it back
+    out._sdn_pe_src = (in_feature, in_feature._version, int(ndegrees), dim, bool(incl_orig), out._version)
     return out
 
 

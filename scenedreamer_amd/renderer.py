@@ -40,6 +40,42 @@ def _lrelu(x):
     return F.leaky_relu(x, 0.2)
 
 
+# ---- per-style constants of the three networks.  `R` is a Renderer or any object with `w` (the reference's parameter names ->
+# ---- device tensors), e.g. the module-level backends of modules.py that read a live nn.Module's parameters.
+def fold_render_net(R, z):
+    """LightningMLP for one style code z [1, style_dim]: ModLinear with N = 1 is a plain layer W' = W * alpha (per input
+    channel) with bias beta (layers.py:247-269); one-hot(label) @ fc_m_a^T + fc_1.bias is a row lookup in a [12, 256] table
+    (use_seg = False: every row is fc_1.bias)."""
+    w = R.w
+    with torch.no_grad():
+        R.mod = {}
+        for i in (2, 3, 4, 5, 6):
+            n = f"render_net.fc_{i}"
+            alpha = F.linear(z, w[n + ".weight_alpha"], w[n + ".bias_alpha"])       # [1, in]
+            beta = F.linear(z, w[n + ".weight_beta"], w[n + ".bias_beta"])          # [1, out]
+            R.mod[i] = ((w[n + ".weight"] * alpha).contiguous(), beta[0].contiguous())
+        b1 = w["render_net.fc_1.bias"][None, :]
+        if "render_net.fc_m_a.weight" in w:
+            R.label_bias = (w["render_net.fc_m_a.weight"].t() + b1).contiguous()
+        else:
+            R.label_bias = b1.expand(12, -1).contiguous()
+    R._fused_style = None
+
+
+def fold_sky_net(R, z):
+    """SKYMLP: the style term fc_z_a(z) [1, 256] joins fc1's bias (gancraft_base.py:158-162)."""
+    with torch.no_grad():
+        R.sky_z = F.linear(z, R.w["sky_net.fc_z_a.weight"])
+    R._fused_sky = None
+
+
+def fold_denoiser(R, z):
+    """RenderCNN: the four FiLM vectors fc_z_cond(z) [1, 1024] (gancraft_base.py:203-204)."""
+    with torch.no_grad():
+        R.cnn_adapt = F.linear(z, R.w["denoiser.fc_z_cond.weight"], R.w["denoiser.fc_z_cond.bias"])
+    R.cnn_calibration = None      # the FiLM vectors changed: the render CNN's precision gate is re-evaluated
+
+
 class Renderer:
     def __init__(self, weights, scene, device="cuda", num_blocks_early_stop=6, sample_depth=3.0, dists_scale=0.25,
                  pad=30):
@@ -112,24 +148,12 @@ class Renderer:
 
     def set_style_code(self, z):
         """Fold an intermediate style code z [1,256] (= style_net(style)) into per-style constants."""
-        w = self.w
         with torch.no_grad():
             z = torch.as_tensor(z, dtype=torch.float32, device=self.dev).reshape(1, -1)
             self.z = z
-            # ModLinear with N=1: W' = W * alpha (per input channel), beta per output (layers.py:247-269)
-            self.mod = {}
-            for i in (2, 3, 4, 5, 6):
-                n = f"render_net.fc_{i}"
-                alpha = F.linear(z, w[n + ".weight_alpha"], w[n + ".bias_alpha"])       # [1, in]
-                beta = F.linear(z, w[n + ".weight_beta"], w[n + ".bias_beta"])          # [1, out]
-                self.mod[i] = ((w[n + ".weight"] * alpha).contiguous(), beta[0].contiguous())
-            # one-hot(label) @ fc_m_a^T + fc_1.bias  ==  row lookup in a [12, 256] table
-            self.label_bias = (w["render_net.fc_m_a.weight"].t() + w["render_net.fc_1.bias"][None, :]).contiguous()
-            self.sky_z = F.linear(z, w["sky_net.fc_z_a.weight"])                         # [1, 256]
-            self.cnn_adapt = F.linear(z, w["denoiser.fc_z_cond.weight"], w["denoiser.fc_z_cond.bias"])
-        self._fused_style = None
-        self._fused_sky = None
-        self.cnn_calibration = None      # the FiLM vectors changed: the render CNN's precision gate is re-evaluated
+            fold_render_net(self, z)
+            fold_sky_net(self, z)
+            fold_denoiser(self, z)
 
     # ------------------------------------------------------------------ stages
     def cast_rays(self, pose, resolution_hw):

@@ -24,7 +24,7 @@ print(f"conv1 {t_1:.3f} ms  conv4a {t_11:.3f} ms  conv4b+proj {t_4b:.3f} ms")
 if cnn.chain:
     from scenedreamer_amd import capi
     t_ch = _time_ms(lambda: capi.check(capi.lib().sdn_conv_chain(buf["a"][0].data_ptr(), buf["a"][1].data_ptr(), cnn.chain_packed.data_ptr(),
-                                                                  cnn.chain_consts.data_ptr(), img.data_ptr(), H, W, 0,
+                                                                  cnn.chain_consts.data_ptr(), img.data_ptr(), None, H, W, 0,
                                                                   capi.current_stream(dev)), "sdn_conv_chain"), 5)
     print(f"conv4a -> conv4b -> conv4 as one chain {t_ch:.3f} ms (as launches: {t_11 + t_4b:.3f} ms)")
     xs = x.reshape(-1, 64).contiguous()
