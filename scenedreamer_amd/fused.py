@@ -161,7 +161,10 @@ def precision_profile(R):
     bounds the change of net_out by 2 * term_eps."""
     ct = getattr(R, "colour_terms", None)
     if ct is None:
-        ct = int(os.environ.get("SDN_MLP_COLOUR_TERMS", "6"))
+        if "SDN_MLP_COLOUR_TERMS" in os.environ:
+            ct = int(os.environ["SDN_MLP_COLOUR_TERMS"])
+        else:       # the per-style decision of Renderer.calibrate_field (6 unless the fp6 corrections cost more than its bound)
+            ct = getattr(R, "colour_terms_auto", None) or 6
     eps = getattr(R, "term_eps", None)
     if eps is None:
         eps = float(os.environ.get("SDN_TERM_EPS", "0"))

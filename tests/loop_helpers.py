@@ -1,0 +1,44 @@
+"""Running the reference's OWN frame loop (Generator.inference_givenstyle, scenedreamer.py:479-632) in an image without cv2 /
+imageio: cv2.imwrite is served by Pillow and imageio.get_writer by a recorder -- host-side file writing, not part of the path."""
+import os
+
+import numpy as np
+import torch
+
+
+def stub_writers():
+    """Returns the list that will receive every frame handed to the video writer."""
+    import cv2
+    import imageio
+    from PIL import Image
+    frames = []
+
+    def imwrite(path, img, params=None):
+        img = np.asarray(img)
+        Image.fromarray(img[..., ::-1] if img.shape[-1] == 3 else img[..., 0]).save(path)      # cv2 takes BGR
+        return True
+
+    class _Rec:
+        def append_data(self, rgb):
+            frames.append(np.asarray(rgb).copy())
+
+        def close(self):
+            pass
+
+    cv2.__dict__["imwrite"] = imwrite
+    cv2.__dict__["IMWRITE_PNG_COMPRESSION"] = 16
+    imageio.__dict__["get_writer"] = lambda path, fps=10: _Rec()
+    return frames
+
+
+def run_reference_loop(G, out_dir, hw, ns, steps, tile_size=64, style_seed=8888, camera_mode=0):
+    """G.inference_givenstyle on the synthetic style; returns the RGB uint8 frames the loop produced (also written as PNGs)."""
+    from scenedreamer_amd import synth
+    frames = stub_writers()
+    style = torch.from_numpy(np.asarray(synth.make_style(style_seed))).cuda()
+    with torch.no_grad():
+        G.inference_givenstyle(style, out_dir, camera_mode=camera_mode, num_samples=ns, tile_size=tile_size, resolution_hw=list(hw),
+                               cam_ang=72, cam_maxstep=steps)
+    rdir = os.path.join(out_dir, "rgb_render")
+    assert len(frames) == steps and all(os.path.exists(os.path.join(rdir, f"{i:05d}.png")) for i in range(steps))
+    return frames

@@ -1,0 +1,296 @@
+"""The fast path behind the reference's own surface, on the MI355X (scenedreamer_amd/modules.py, dropin.py).
+
+Module level: LightningMLP / SKYMLP / RenderCNN with the reference's constructor, parameters and forward signature, forward
+on the MFMA kernels (sdn_render_mlp, sdn_sky_mlp, MfmaCNN) -- against their own composite (plain PyTorch fp32) forward on
+the same weights, which tests/test_dropin_cpu.py pins on the reference's classes.
+Generator level: the UNMODIFIED imaginaire generator with `install_shims(fast=True)` -- _forward_perpix / _forward_global on
+the goldens, and its own inference_givenstyle frame loop against this package's renderer."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+def _load(module, weights, prefix):
+    sd = {k[len(prefix):]: torch.as_tensor(np.asarray(v)) for k, v in weights.items() if k.startswith(prefix)}
+    module.load_state_dict(sd)
+    return module.cuda().eval()
+
+
+@pytest.fixture(scope="module")
+def nets(weights_full):
+    from scenedreamer_amd import modules
+    mlp = _load(modules.LightningMLP(128, 256, 0, mask_dim=12, out_channels_s=1, out_channels_c=64), weights_full, "render_net.")
+    sky = _load(modules.SKYMLP(33, 256, 64), weights_full, "sky_net.")
+    cnn = _load(modules.RenderCNN(64, 256), weights_full, "denoiser.")
+    for m in (mlp, sky, cnn):
+        for p in m.parameters():
+            p.requires_grad_(False)          # as inference.py does (:63-64): nothing asks for gradients
+    return mlp, sky, cnn
+
+
+def _style_code(seed=0):
+    g = golden("style_globalenc.npz")
+    z = torch.from_numpy(g["z"]).cuda().reshape(1, -1)
+    if seed:
+        z = z + 0.25 * torch.randn(z.shape, generator=torch.Generator().manual_seed(seed)).cuda()
+    return z
+
+
+@pytest.mark.parametrize("shape", [(1, 7, 9, 5), (1, 40, 56, 12), (2, 3, 5, 4), (1, 1, 1, 1)])
+def test_lightning_mlp_module_on_the_mfma_kernel(nets, shape):
+    """LightningMLP.forward (layers.py:92-126) -> sdn_render_mlp, ragged row counts (not multiples of 32 / 256), batch 2."""
+    mlp = nets[0]
+    n, h, w, ms = shape
+    gen = torch.Generator().manual_seed(h * w)
+    x = (torch.rand((n, h, w, ms, 128), generator=gen) - 0.5).cuda() * 0.6          # hash-grid features: |x| <= ~0.5 x 8 corners' blend
+    lab = torch.randint(0, 12, (n, h, w, ms, 1), generator=gen).cuda()
+    m = torch.zeros((n, h, w, ms, 12), device="cuda").scatter_(-1, lab, 1.0)
+    z = torch.cat([_style_code(i) for i in range(n)], dim=0)
+    with torch.no_grad():
+        sigma, c = mlp(x, None, z, m)
+        assert mlp.native_reason(x, None, z, m) is None
+        ref_s, ref_c = mlp._forward_composite(x, None, z, m)
+    assert sigma.shape == ref_s.shape == (n, h, w, ms, 1) and c.shape == ref_c.shape == (n, h, w, ms, 64)
+    es = float((sigma - ref_s).abs().max() / max(1.0, float(ref_s.abs().max())))
+    ec = float((c - ref_c).abs().max())
+    print(f"LightningMLP {shape}: sigma rel err {es:.2e} (|sigma| <= {float(ref_s.abs().max()):.2f}), colour abs err {ec:.2e}")
+    assert es < 2e-4 and ec < 2e-4
+
+
+def test_lightning_mlp_notices_new_weights_and_styles(nets):
+    """The packed weights follow in-place parameter updates and a changed style code (Backend.bind / style)."""
+    from scenedreamer_amd import modules
+    mlp = nets[0]
+    mine = modules.LightningMLP(128, 256, 0, mask_dim=12, out_channels_s=1, out_channels_c=64)
+    mine.load_state_dict(mlp.state_dict())
+    mine = mine.cuda().eval()
+    for p in mine.parameters():
+        p.requires_grad_(False)
+    x = (torch.rand((1, 5, 6, 4, 128), generator=torch.Generator().manual_seed(3)) - 0.5).cuda()
+    m = torch.zeros((1, 5, 6, 4, 12), device="cuda")
+    m[..., 4] = 1
+    z = _style_code()
+    with torch.no_grad():
+        a = mine(x, None, z, m)
+        mine.fc_3.weight.mul_(1.5)
+        mine.fc_1.bias.add_(0.05)
+        b = mine(x, None, z, m)
+        rb = mine._forward_composite(x, None, z, m)
+        z.mul_(0.5)
+        c = mine(x, None, z, m)
+        rc = mine._forward_composite(x, None, z, m)
+    assert float((a[1] - b[1]).abs().max()) > 1e-3
+    assert float((b[1] - rb[1]).abs().max()) < 2e-4 and float((c[1] - rc[1]).abs().max()) < 2e-4
+
+
+def test_sky_mlp_module_encoded_rows_and_tagged_directions(nets):
+    """SKYMLP.forward (gancraft_base.py:150-169): (a) any [.., 33] rows -> sky_kernel<PRE>; (b) the output of this package's
+    voxlib.positional_encoding -> the kernel encodes the ray directions itself; (c) an in-place edit of that tensor voids the tag."""
+    from scenedreamer_amd import ops
+    sky = nets[1]
+    z = _style_code()
+    gen = torch.Generator().manual_seed(5)
+    rd = torch.nn.functional.normalize(torch.randn((1, 37, 53, 1, 3), generator=gen), dim=-1).cuda()
+    with torch.no_grad():
+        pe = ops.positional_encoding(rd.expand(-1, -1, -1, 1, -1).contiguous(), 5, -1, True)
+        ref = sky._forward_composite(pe, z)
+        tagged = sky(pe, z)                          # (b)
+        assert "_sdn_last_frame" in sky.__dict__ and sky.__dict__["_sdn_last_frame"]["n_rays"] == 37 * 53
+        plain = sky(pe.clone(), z)                   # (a): a copy carries no tag
+        rows = (torch.rand((1, 11, 33), generator=gen) * 2 - 1).cuda()
+        r2, ref2 = sky(rows, z), sky._forward_composite(rows, z)
+        pe2 = ops.positional_encoding(rd.contiguous(), 5, -1, True)
+        pe2[..., 3:6] += 0.25                        # (c) no longer the encoding of rd
+        edited, ref3 = sky(pe2, z), sky._forward_composite(pe2, z)
+    assert tagged.shape == ref.shape == (1, 37, 53, 1, 64)
+    for name, a, b in (("tagged", tagged, ref), ("encoded rows", plain, ref), ("arbitrary rows", r2, ref2), ("edited", edited, ref3)):
+        e = float((a - b).abs().max())
+        print(f"SKYMLP {name}: max abs err {e:.2e}")
+        assert e < 3e-4, name
+    assert float((edited - tagged).abs().max()) > 1e-3
+
+
+@pytest.mark.parametrize("hw", [(40, 56), (33, 71)])
+def test_render_cnn_module_returns_the_pre_tanh_image(nets, hw):
+    """RenderCNN.forward (gancraft_base.py:202-225) returns conv4's output; _forward_global applies tanh (:598-603)."""
+    cnn = nets[2]
+    z = _style_code()
+    x = (torch.rand((1, 64, hw[0], hw[1]), generator=torch.Generator().manual_seed(9)) * 2 - 1).cuda()
+    with torch.no_grad():
+        raw = cnn(x, z)
+        ref = cnn._forward_composite(x, z)
+    assert cnn.native_reason(x, z) is None and raw.shape == ref.shape == (1, 3, hw[0], hw[1])
+    e = float((raw - ref).abs().max())
+    et = float((torch.tanh(raw) - torch.tanh(ref)).abs().max())
+    print(f"RenderCNN {hw}: pre-tanh max abs err {e:.2e} (|y| <= {float(ref.abs().max()):.2f}), after tanh {et:.2e}")
+    assert et < TOL and e < 5e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_field_render_aux_outputs_and_device_camera(weights_full, scene256):
+    """sdn_field_render's additions: cam_ori read from device memory == host values (bitwise); depth_out == the sample
+    depths of the stand-alone sampling op (the same device function); weights_out: zero for rays without a hit, non-negative,
+    summing to at most 1 per ray (the generator-level test compares them with the reference's own method)."""
+    from scenedreamer_amd import camera, fused, ops, synth
+    from scenedreamer_amd.renderer import Renderer
+    R = Renderer(weights_full, scene256, "cuda")
+    R.set_style(synth.make_style(8888))
+    pose = camera.eval_camera_poses(scene256, maxstep=8)[2]
+    ns = 12
+    with torch.no_grad():
+        vid, d2, rd, (H0, W0) = R.cast_rays(pose, (48, 64))
+        n = H0 * W0
+        vid, d2, rd = vid.view(n, R.M), d2.view(2, n, R.M), rd.view(n, 3)
+        sky_c, sky_avg = fused.sky_fused(R, rd)
+        host = fused.field_render(R, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, ns)
+        dev = fused.field_render(R, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32).cuda(), sky_c, sky_avg, ns)
+        aux = {}
+        with_aux = fused.field_render(R, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, ns, aux=aux)
+        depth, _, _ = ops.sample_depth_batched(d2.view(1, 2, H0, W0, R.M, 1), ns + 1, deterministic=True, use_box_boundaries=False,
+                                               sample_depth=R.sample_depth)
+        depth = depth.view(n, ns)
+        depth = torch.where(torch.isnan(depth) | torch.isinf(depth), torch.zeros_like(depth), depth)
+    assert torch.equal(host, dev) and torch.equal(host, with_aux)
+    w, dp = aux["weights"], aux["depth"]
+    assert tuple(w.shape) == tuple(dp.shape) == (n, ns)
+    hit = vid[:, 0] != 0
+    assert float(w[~hit].abs().max()) == 0.0 and bool((w >= 0).all()) and float(w.sum(dim=1).max()) <= 1.0 + 1e-5
+    assert int(hit.sum()) > 100 and float(w[hit].sum(dim=1).max()) > 0.05
+    assert torch.equal(dp, depth)
+
+
+def _generator(weights_full, scene256, fast, aux=False):
+    from oracle import ref_harness as RH
+    RH.install("hip-fast" if fast else "hip")
+    G, _ = RH.build_generator(weights_full, scene256)
+    G = G.cuda()
+    for p in G.parameters():
+        p.requires_grad_(False)
+    G.voxel.voxel_t = scene256.voxel_t.cuda()
+    G.voxel.current_height_map = scene256.current_height_map.cuda()
+    G.voxel.current_semantic_map = scene256.current_semantic_map.cuda()
+    if fast:
+        from scenedreamer_amd import dropin
+        dropin.binding(G, aux=aux)
+    return G, RH
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("aux", [False, True])
+def test_unmodified_generator_methods_on_the_fused_kernels(scene256, weights_full, aux):
+    """Generator._forward_perpix / _forward_global of the UNMODIFIED reference with install_shims(fast=True): goldens recorded
+    from the reference itself, and -- aux -- the extra return values against the reference's own method on the same inputs."""
+    import sys
+    G, RH = _generator(weights_full, scene256, fast=True, aux=aux)
+    from scenedreamer_amd import dropin
+    voxlib = sys.modules["voxlib"]
+    b = dropin.binding(G)
+    for tag in "abc":
+        g = golden(f"field_{tag}.npz")
+        hw, ns = [int(v) for v in g["resolution_hw"]], int(g["num_samples"])
+        RH.set_inference_overrides(G, ns, hw)
+        z, ge = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(g["global_enc"]).cuda()
+        cam = torch.from_numpy(g["cam_ori"])[None].cuda()
+        with torch.no_grad():
+            vid, d2, rd = voxlib.ray_voxel_intersection_perspective(
+                G.voxel.voxel_t, torch.from_numpy(g["cam_ori"]), torch.from_numpy(g["cam_dir"]),
+                torch.from_numpy(g["cam_up"]), float(g["cam_f"]), [float(v) for v in g["cam_c"]], G.cam_res, 6)
+            vid, d2, rd = vid.unsqueeze(0), d2.unsqueeze(0), rd.unsqueeze(0)
+            sky_in = voxlib.positional_encoding(rd.expand(-1, -1, -1, 1, -1).contiguous(), G.pe_params_sky[0], -1, G.pe_params_sky[1])
+            G.sky_avg = torch.mean(G.sky_net(sky_in, z), dim=[1, 2], keepdim=True)
+            before = dict(b.stats)
+            out = G._forward_perpix(None, vid, d2.clone() if aux else d2, rd, cam, z, ge)
+            img, raw = G._forward_global(out[0], z)
+            ref = G._forward_perpix_reference(None, vid, d2.clone(), rd, cam, z, ge) if aux else None
+        del G.sky_avg
+        assert b.stats["perpix_fast"] == before["perpix_fast"] + 1 and b.stats["global_fast"] == before["global_fast"] + 1, b.stats
+        assert len(out) == 12
+        np.testing.assert_allclose(out[0].cpu().numpy(), g["net_out"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(img.cpu().numpy(), g["image"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(torch.tanh(raw).cpu().numpy(), img.cpu().numpy(), rtol=0, atol=1e-6)
+        if not aux:
+            assert all(o is None for o in out[1:])
+            assert b.stats["tiles_in_place"] == before["tiles_in_place"] + 1       # d2 is the frame array itself: read in place
+            continue
+        names = dropin.PERPIX_OUTPUTS
+        # new_dists, rand_depth: the reference's torch ops on the GPU accumulate the box lengths in float32, the kernel like
+        # the CPU reference in double (mc_utils.py:102 on a CPU tensor): an ulp of a depth of ~100 voxels is 8e-6
+        np.testing.assert_allclose(out[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=0, atol=1e-6, err_msg=names[1])
+        np.testing.assert_allclose(out[4].cpu().numpy(), ref[4].cpu().numpy(), rtol=0, atol=1e-4, err_msg=names[4])
+        for i in (9, 10):                                  # sky_mask, sky_only_mask: exact
+            assert torch.equal(out[i], ref[i]), names[i]
+        assert out[11].dtype == ref[11].dtype == torch.int64 and float((out[11] != ref[11]).float().mean()) < 1e-3, names[11]
+        np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].cpu().numpy(), rtol=0, atol=TOL, err_msg="weights")
+        np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].cpu().numpy(), rtol=0, atol=TOL, err_msg="total_weights_raw")
+        print(f"golden {tag}: weights max abs diff vs the reference's own method {float((out[2] - ref[2]).abs().max()):.2e}")
+
+
+@pytest.mark.needs_reference
+def test_unsupported_calls_fall_to_the_reference_method_on_hip_ops(scene256, weights_full):
+    """A call the fused kernel does not implement (box-boundary sampling) is served by the reference's own _forward_perpix --
+    on the native modules -- and counted with its reason."""
+    import sys
+    G, RH = _generator(weights_full, scene256, fast=True)
+    from scenedreamer_amd import dropin
+    voxlib = sys.modules["voxlib"]
+    g = golden("field_a.npz")
+    hw, ns = [int(v) for v in g["resolution_hw"]], int(g["num_samples"])
+    RH.set_inference_overrides(G, ns, hw)
+    z, ge = torch.from_numpy(g["z"]).cuda(), torch.from_numpy(g["global_enc"]).cuda()
+    with torch.no_grad():
+        vid, d2, rd = voxlib.ray_voxel_intersection_perspective(
+            G.voxel.voxel_t, torch.from_numpy(g["cam_ori"]), torch.from_numpy(g["cam_dir"]), torch.from_numpy(g["cam_up"]),
+            float(g["cam_f"]), [float(v) for v in g["cam_c"]], G.cam_res, 6)
+        vid, d2, rd = vid.unsqueeze(0), d2.unsqueeze(0), rd.unsqueeze(0)
+        fast = G._forward_perpix(None, vid, d2.clone(), rd, torch.from_numpy(g["cam_ori"])[None].cuda(), z, ge)[0]
+        # the reference's method itself, module by module on the MFMA kernels, gives the same net_out
+        slow = G._forward_perpix_reference(None, vid, d2.clone(), rd, torch.from_numpy(g["cam_ori"])[None].cuda(), z, ge)[0]
+        assert G.render_net.__dict__.get("_sdn_backend") is not None          # LightningMLP ran natively inside it
+        G.sample_use_box_boundaries = True
+        G.num_samples = ns + 6
+        b = dropin.binding(G)
+        n0 = b.stats["perpix_reference"]
+        out = G._forward_perpix(None, vid, d2.clone(), rd, torch.from_numpy(g["cam_ori"])[None].cuda(), z, ge)
+    assert b.stats["perpix_reference"] == n0 + 1 and b.stats["why"].get("sample_use_box_boundaries") == 1
+    assert out[0].shape == fast.shape and all(o is not None for o in out)
+    np.testing.assert_allclose(slow.cpu().numpy(), g["net_out"], rtol=0, atol=TOL)
+    np.testing.assert_allclose(fast.cpu().numpy(), slow.cpu().numpy(), rtol=0, atol=TOL)
+
+
+@pytest.mark.needs_reference
+@pytest.mark.parametrize("tile", [64, 1024])
+def test_unmodified_inference_loop_on_the_fused_kernels(scene256, weights_full, tmp_path, tile):
+    """Generator.inference_givenstyle (scenedreamer.py:479-632), UNCHANGED, with install_shims(fast=True): 2 x 2 tiles (tile_size
+    64: every tile read in place from the frame arrays, sky features of the pre-pass reused) and one tile per frame (tile_size >=
+    frame) -- against this package's renderer on the same trajectory: uint8 frames agree to one level."""
+    from loop_helpers import run_reference_loop
+    from scenedreamer_amd import camera, dropin, synth
+    from scenedreamer_amd.output import to_uint8_hwc
+    from scenedreamer_amd.renderer import Renderer
+    G, _ = _generator(weights_full, scene256, fast=True)
+    hw, ns, steps = [72, 104], 12, 3
+    frames = run_reference_loop(G, str(tmp_path / "ref"), hw, ns, steps, tile_size=tile)
+    b = dropin.binding(G)
+    tiles = 4 if tile == 64 else 1
+    assert b.stats["perpix_fast"] == steps * tiles and b.stats["perpix_reference"] == 0 and b.stats["global_fast"] == steps * tiles, b.stats
+    assert b.stats["tiles_in_place"] == steps * tiles and b.stats["sky_reused"] == steps * tiles, b.stats
+    R = Renderer(weights_full, scene256, "cuda")
+    R.set_style(synth.make_style(8888))
+    poses = camera.eval_camera_poses(scene256, maxstep=steps, pattern=0, cam_ang=72)
+    worst, off = 0, 0.0
+    for f, img in enumerate(R.render_frames(poses, tuple(hw), ns, mode="fused")):
+        mine = to_uint8_hwc(img).cpu().numpy().astype(np.int32)
+        d = np.abs(frames[f].astype(np.int32) - mine)
+        assert frames[f].shape == mine.shape == (hw[0], hw[1], 3) and frames[f].std() > 5
+        worst, off = max(worst, int(d.max())), max(off, float((d > 0).mean()))
+    print(f"inference_givenstyle (unmodified, fast shims, tile_size {tile}) vs scenedreamer_amd frames: max |diff| {worst} level, "
+          f"{100 * off:.2f} % of the values differ; stats {b.stats}")
+    assert worst <= 1 and off < 0.2
+    assert os.path.exists(os.path.join(str(tmp_path / "ref"), "rgb_render", "00002.png"))

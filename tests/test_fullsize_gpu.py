@@ -64,6 +64,36 @@ def test_rvip_skipping_is_exact_at_full_size(big):
         assert torch.equal(a[2].view(torch.int32), b[2].view(torch.int32))
 
 
+def test_rvip_bit_exact_vs_reference_source_at_the_headline_size(big):
+    """The integer path AT the benchmark size: voxel_id / depth2 / raydirs of the 2048^2 scene, padded 570 x 990 frame, the 20
+    poses bench.py times (every 2nd of the 40-pose orbit) -- bit for bit against the reference's OWN ray_voxel_intersection.cu
+    compiled for the host (oracle/_ref, :52-235), for the int32 volume and for the compact uint8 volume bench.py walks."""
+    from oracle import build_ref as BR
+    if not BR.built("nofma"):
+        pytest.skip("oracle/_ref not present in this snapshot")
+    from conftest import bits
+    from oracle import ref_native as RN
+    from scenedreamer_amd import ops, scene as scene_mod
+    from scenedreamer_amd.camera import frame_intrinsics
+    R, scene, poses = big
+    vox_np = scene.voxel_t.cpu().numpy()
+    comp = scene_mod.to_compact(scene)
+    u8, pal = comp.voxel_u8.cuda(), comp.palette.cuda().contiguous()
+    hits = 0
+    for pi in range(0, 40, 2):
+        ori, d, up, cf = poses[pi]
+        f, c, cam_res = frame_intrinsics(cf, (540, 960), R.pad)
+        assert list(cam_res) == [570, 990]
+        rid, rd2, rrd = RN.rvip(vox_np, ori.numpy(), d.numpy(), up.numpy(), f, c, cam_res, R.M)
+        for name, out in (("int32", ops.ray_voxel_intersection_perspective(scene.voxel_t, ori, d, up, f, c, cam_res, R.M)),
+                          ("uint8", ops.ray_voxel_intersection_perspective(u8, ori, d, up, f, c, cam_res, R.M, palette=pal))):
+            assert np.array_equal(out[0].cpu().numpy(), rid), f"pose {pi} ({name} volume): voxel ids differ"
+            assert np.array_equal(bits(out[1].cpu().numpy()), bits(rd2)), f"pose {pi} ({name} volume): depths differ"
+            assert np.array_equal(bits(out[2].cpu().numpy()), bits(rrd)), f"pose {pi} ({name} volume): ray directions differ"
+        hits += int((rid[..., 0, 0] != 0).sum())
+    assert hits > 0.3 * 20 * 570 * 990
+
+
 def test_pipelined_trajectory_equals_frame_by_frame(big):
     """render_frames (ray casting of frame i+1 on a second stream beside frame i) yields the same bits as render_frame."""
     R, scene, poses = big

@@ -19,8 +19,12 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = {"field.hip": ["-fno-slp-vectorize"], "cnn.hip": []}
-# (mlp_kernel<DBG, CT, FUSED>: ...Lb1E = field_kernel, the single-kernel field: no input prefetch, a[190:255] are ordinary registers)
-KERNELS = ("mlp_kernelILi0ELi3ELb0E", "mlp_kernelILi0ELi2ELb0E", "mlp_kernelILi0ELi6ELb0E", "mlp_kernelILi0ELi3ELb1E", "mlp_kernelILi0ELi6ELb1E", "sky_kernelILi0ELi0", "sky_kernelILi0ELi1", "chain_kernelENS_11ChainParamsE", "head_kernelENS_10HeadParamsE", "conv_kernelILi9ELi0ELi3ELi16E", "conv_kernelILi9ELi0ELi3ELi27E", "conv_kernelILi9ELi0ELi3ELi255E",
+# (mlp_kernel<DBG, CT, MODE>: MODE 0 = features from encode_kernel's buffer (the only one with the AGPR input prefetch), 1 = field_kernel,
+#  2 = field_kernel + per-sample outputs, 3 = LightningMLP.forward as an op; sky_kernel<DBG, SMX, PRE>)
+KERNELS = ("mlp_kernelILi0ELi3ELi0E", "mlp_kernelILi0ELi2ELi0E", "mlp_kernelILi0ELi6ELi0E", "mlp_kernelILi0ELi3ELi1E", "mlp_kernelILi0ELi6ELi1E",
+           "mlp_kernelILi0ELi3ELi2E", "mlp_kernelILi0ELi6ELi2E", "mlp_kernelILi0ELi3ELi3E", "mlp_kernelILi0ELi6ELi3E",
+           "sky_kernelILi0ELi0ELb0E", "sky_kernelILi0ELi1ELb0E", "sky_kernelILi0ELi0ELb1E", "chain_kernelENS_11ChainParamsE", "head_kernelENS_10HeadParamsE",
+           "conv_kernelILi9ELi0ELi3ELi16E", "conv_kernelILi9ELi0ELi3ELi27E", "conv_kernelILi9ELi0ELi3ELi255E",
            "conv_kernelILi9ELi0ELi1ELi0E", "conv_kernelILi9ELi0ELi1ELi16E", "conv_kernelILi9ELi0ELi1ELi27E", "conv_kernelILi9ELi0ELi1ELi255E",
            "conv_kernelILi1ELi0ELi3ELi16E", "conv_kernelILi1ELi0ELi3ELi255E")
 REG = re.compile(r"\b([va])\[(\d+):(\d+)\]|\b([va])(\d+)\b")
@@ -194,12 +198,15 @@ def main():
                 start = next((i for i, l in enumerate(text) if l.startswith("_Z") and k in l and l.rstrip().endswith(":") or
                               (l.startswith("_Z") and k in l and ": " in l)), None)
                 if start is None:
+                    if src == "field.hip" and not k.startswith("conv_kernel"):
+                        print(f"{src}:{k}: NOT FOUND in the compiled ISA (kernel renamed? update KERNELS)")
+                        bad += 1
                     continue
                 end = next(i for i in range(start, len(text)) if "s_endpgm" in text[i])
                 body = list(enumerate(text[start:end], start + 1))
                 n, problems = check_kernel(k, body)
                 print(f"{src}:{k}: {n} LDS reads replayed, {len(problems)} hazard(s)")
-                if k.startswith("mlp_kernel") and k.endswith("ELb0E"):
+                if k.startswith("mlp_kernel") and k.endswith("ELi0E"):
                     n2, p2, nf = check_prefetch_agprs(body)
                     print(f"{src}:{k}: {n2} instructions on the prefetch AGPRs a[190:255]: {nf} compiler-generated "
                           f"(spill space while the registers are dead), {len(p2)} violation(s)")

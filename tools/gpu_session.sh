@@ -1,0 +1,32 @@
+#!/bin/bash
+# One parameterised GPU session script (replaces the per-run run_rNN_*.sh files of earlier rounds):
+#   tools/gpu_session.sh <label> <step> [<step> ...]
+# run on the GPU box through gpurun; every step logs under gpurun_out/<label>_<step>.*  Steps:
+#   new        the tests added in round 4 (drop-in surface, precision gates)
+#   core       render / fused / ops / dist tests
+#   full       the whole `-m gpu` suite
+#   bench      bench.py headline (20 steps) without the CPU leg
+#   benchfull  bench.py exactly as the driver runs it (defaults)
+#   dropin     bench.py --only dropin
+#   prof       tools/prof_final.sh: full suite + driver bench + rocprofv3 kernel trace + PMC passes, summaries -> gpurun_out/<label>_*
+#   any other word: executed as tools/<word>.sh if it exists
+set -u
+cd "$(dirname "$0")/.."
+label=$1; shift
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/${label}_build.log 2>&1 || { echo "BUILD FAILED"; tail -20 gpurun_out/${label}_build.log; }
+for step in "$@"; do
+  echo "=== $step ($(date +%T))"
+  case $step in
+    new)   timeout 1500 python -m pytest tests/test_dropin_gpu.py tests/test_precision_gates_gpu.py -q -m gpu -s --durations=10 > gpurun_out/${label}_new.log 2>&1; echo "rc=$?"; tail -25 gpurun_out/${label}_new.log ;;
+    core)  timeout 1500 python -m pytest tests/test_render_gpu.py tests/test_fused_gpu.py tests/test_ops_gpu.py tests/test_dist_gpu.py -q -m gpu --durations=10 > gpurun_out/${label}_core.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/${label}_core.log ;;
+    full)  timeout 2400 python -m pytest tests -q -m gpu -s --durations=25 > gpurun_out/${label}_full.log 2>&1; echo "rc=$?"; tail -40 gpurun_out/${label}_full.log ;;
+    bench) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${label}_bench.json 2> gpurun_out/${label}_bench.err; echo "rc=$?"; tail -c 1500 gpurun_out/${label}_bench.json; tail -5 gpurun_out/${label}_bench.err ;;
+    benchfull) timeout 900 python bench.py > gpurun_out/${label}_benchfull.json 2> gpurun_out/${label}_benchfull.err; echo "rc=$?"; tail -c 3000 gpurun_out/${label}_benchfull.json; tail -5 gpurun_out/${label}_benchfull.err ;;
+    dropin) timeout 900 python bench.py --only dropin > gpurun_out/${label}_dropin.json 2> gpurun_out/${label}_dropin.err; echo "rc=$?"; tail -c 3000 gpurun_out/${label}_dropin.json; tail -8 gpurun_out/${label}_dropin.err ;;
+    prof)  bash tools/prof_final.sh "$(cat tools/.commit 2>/dev/null)" $label ;;
+    *)     if [ -x tools/$step.sh ]; then tools/$step.sh $label; else echo "unknown step $step"; fi ;;
+  esac
+done
+echo "=== done ($(date +%T))"
