@@ -19,8 +19,15 @@ Other BASELINE.json configurations are one command each:
                                    the only exchange is the all_reduce of the frame-wide sky mean ("scaling": "strong")
 (--bench-mode frames|tile-parallel, --cam-maxstep, --height/--width/--samples give the same control by hand.)
 
+`--gpus N` (N > 1) as a PLAIN command (no WORLD_SIZE in the environment) re-executes itself under
+`python -m torch.distributed.run --nproc-per-node N`; the world size must equal --gpus, and with the RCCL backend N GPUs
+must be visible -- anything else stops with an error instead of reporting a smaller job.
+
 Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` for the dominant kernel (the field MLP),
-`roofline_grid_sampler` and, at N=1, `cpu_baseline` (the CPU oracle timed on this box's host cores).
+`roofline_grid_sampler`, `roofline_cnn`, `roofline_rvip` and, at N=1, `cpu_baseline` (the reference / the CPU oracle timed on
+this box's host cores), `precision` (measured error + the per-style gates), `dropin` (the UNMODIFIED reference generator's
+inference_givenstyle loop on the fast shims, when the reference's Python tree is present) and `other_configs` (BASELINE
+configs 3 and 5 on this GPU: a few frames each + one oracle tile).  --only dropin|other prints just that record.
 """
 import argparse
 import json
@@ -88,9 +95,16 @@ def parse():
                          "which is how this script's multi-rank path is exercised on a one-GPU box -- timings are then meaningless)")
     ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
                     help="BASELINE.json configs[i-1]: sets resolution / samples / cam_maxstep / bench mode / steps")
+    ap.add_argument("--only", default=None, choices=["dropin", "other"],
+                    help="print only that extra record (JSON line): `dropin` = the unmodified reference generator's inference loop on "
+                         "the fast shims; `other` = BASELINE configs 3 and 5 on one GPU")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the `dropin` record")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` record")
+    ap.add_argument("--dropin-frames", type=int, default=12, help="frames of the reference's loop per tile size in the `dropin` record")
     args = ap.parse_args()
     if args.profile:
-        args.no_extras = args.no_cpu_baseline = True
+        args.no_extras = args.no_cpu_baseline = args.no_dropin = args.no_other_configs = True
+        os.environ.setdefault("SDN_FIELD_GATE", "0")    # no calibration launches in the trace (scenedreamer_amd.renderer.FIELD_GATE)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.config == 3:
         args.height, args.width, args.samples, args.no_extras = 1080, 1920, 40, True
@@ -213,6 +227,205 @@ def _reference_tiles(weights, scene, vox, pose, hw, ns, z, genc, picks, pad=30, 
     return t_frame, t_tiles, got
 
 
+def dropin_record(args, weights, scene, dev):
+    """The UNMODIFIED reference generator -- imaginaire.generators.scenedreamer.Generator.inference_givenstyle, its own frame loop
+    (scenedreamer.py:479-632) -- on `scenedreamer_amd.install_shims(fast=True)`: voxlib / gridencoder served by the HIP ops, its
+    LightningMLP / SKYMLP / RenderCNN classes and its _forward_perpix / _forward_global methods bound to the fused kernels from
+    outside (scenedreamer_amd/dropin.py).  Needs the reference's Python tree at run time: /root/reference in the build container,
+    the staged archive oracle/_ref/pytree.zip (unchanged files, oracle/build_ref.stage_pytree) on the GPU box; the loader
+    (oracle/ref_harness) only locates / unpacks it and supplies the cv2 / imageio stand-ins this image lacks -- nothing of the CPU
+    oracle runs here.  Frames/s are taken between the completion times of the loop's own frames (after its device -> host copy
+    and uint8 conversion; PNG / MP4 encoders are no-ops: host-side file encoding is excluded, as for the headline)."""
+    import tempfile
+    try:
+        from oracle import ref_harness as RH
+    except ImportError as e:
+        return {"skipped": f"oracle/ref_harness not importable: {e}"}
+    if not RH.available():
+        return {"skipped": "the reference's Python tree is not on this machine (neither /root/reference nor oracle/_ref/pytree.zip)"}
+    from scenedreamer_amd import dropin, synth
+    RH.install("hip-fast")
+    import cv2
+    import imageio
+    stamps = []
+
+    class _Writer:
+        def append_data(self, rgb):
+            stamps.append(time.perf_counter())
+
+        def close(self):
+            pass
+
+    cv2.__dict__["imwrite"] = lambda path, img, params=None: True
+    cv2.__dict__["IMWRITE_PNG_COMPRESSION"] = 16
+    imageio.__dict__["get_writer"] = lambda path, fps=10: _Writer()
+    sc = synth.Scene()
+    sc.voxel_t = scene.voxel_t.to(dev)                    # the int32 volume the reference's generator holds (pcg_gen.py:173)
+    sc.heightmap, sc.trans_mat, sc.sample_size = scene.heightmap, scene.trans_mat, scene.sample_size
+    sc.current_height_map, sc.current_semantic_map = scene.current_height_map.to(dev), scene.current_semantic_map.to(dev)
+    G, _ = RH.build_generator(weights, sc)
+    G = G.to(dev).eval()
+    for prm in G.parameters():
+        prm.requires_grad = False                          # inference.py:63-64
+    v = G.voxel
+    v.voxel_t, v.current_height_map, v.current_semantic_map = sc.voxel_t, sc.current_height_map, sc.current_semantic_map
+    style = torch.from_numpy(np.asarray(synth.make_style(8888))).to(dev)
+    hw = [args.height, args.width]
+    out = {"what": "imaginaire.generators.scenedreamer.Generator.inference_givenstyle, unmodified, on install_shims(fast=True)",
+           "workload": f"{args.width}x{args.height}, num_samples={args.samples}, scene_size={args.scene_size}, camera_mode 0, "
+                       f"cam_maxstep={args.dropin_frames}", "runs": [],
+           "timing": "frames/s = (frames - 1) / (completion of the last - completion of the first frame), each completion taken "
+                     "when the loop hands the frame to its video writer (after its own D2H copy + uint8 conversion); the first "
+                     "call with 3 frames is the warm-up; PNG / MP4 encoders are no-ops"}
+    with tempfile.TemporaryDirectory() as tmp, torch.no_grad():
+        for tile in (128, 1024):
+            kw = dict(camera_mode=0, num_samples=args.samples, tile_size=tile, resolution_hw=hw, cam_ang=72)
+            G.inference_givenstyle(style, os.path.join(tmp, f"warm{tile}"), cam_maxstep=3, **kw)
+            torch.cuda.synchronize()
+            b = dropin.binding(G)
+            before = {k: v for k, v in b.stats.items() if k != "why"}
+            del stamps[:]
+            t0 = time.perf_counter()
+            G.inference_givenstyle(style, os.path.join(tmp, f"run{tile}"), cam_maxstep=args.dropin_frames, **kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n = len(stamps)
+            fps = (n - 1) / (stamps[-1] - stamps[0]) if n > 1 else None
+            tiles = ((hw[0] + tile - 1) // tile) * ((hw[1] + tile - 1) // tile)
+            out["runs"].append({"tile_size": tile, "tiles_per_frame": tiles, "frames": n, "frames_per_s": fps,
+                                "ms_per_frame": 1000.0 / fps if fps else None, "whole_call_s": t1 - t0,
+                                "note": ("the reference's default tiling (inference.py passes no tile_size)" if tile == 128 else
+                                         "tile_size >= frame -- an argument of the unmodified method: one _forward_perpix / "
+                                         "_forward_global call per frame"),
+                                "calls": {k: v - before[k] for k, v in b.stats.items() if k != "why"}, "reference_path_reasons": dict(b.stats["why"])})
+    out["cnn_gate"] = b.B.cnn_calibration
+    del G
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_configs(args, R, weights, scene, poses, dev):
+    """BASELINE configs 3 (1920x1080x40) and 5 (3840x2160x40; on ONE GPU: the tile-parallel path with a single band) on the
+    benchmark scene: a few frames each, after the headline's timed region, + the max abs error of one tile of the
+    reference's tile grid against the CPU oracle (reference-literal evaluation of that tile)."""
+    from oracle import field_ref as FR
+    from scenedreamer_amd import dist as sdist
+    from scenedreamer_amd.camera import tile_grid
+    from scenedreamer_amd.renderer import load_label_lut
+    lut = load_label_lut()["lut"]
+    vox = scene.voxel_t.cpu().numpy()
+    z, genc = R.z.cpu().numpy(), R.global_enc.cpu().numpy()
+    torch.set_num_threads(min(CPU_THREADS_MAX, 64))
+    recs = []
+    for cfg, hw, ns, frames in ((3, (1080, 1920), 40, 3), (5, (2160, 3840), 40, 2)):
+        sel = [poses[(7 * k + 3) % len(poses)] for k in range(frames + 1)]
+        probe = {}
+        torch.cuda.synchronize()
+        if cfg == 3:
+            it = R.render_frames(sel, hw, ns, mode="fused", probe=probe)
+            imgs = []
+            for k, im in enumerate(it):
+                if k == 0:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                imgs.append(im if k == frames else None)
+            torch.cuda.synchronize()
+            ms = 1000.0 * (time.perf_counter() - t0) / frames
+            last = imgs[-1]
+            field_ms = float(np.mean([a.elapsed_time(b) for a, b in probe["mlp_kernel"][1:]])) if probe.get("mlp_kernel") else None
+            B, hit, ev = R.field_work(sel[1:], hw, ns, "minimal")
+            field_frac = (ev["evaluated_samples"] * 754176 / (field_ms * 1e-3) / 1e12 / 2500.0) if field_ms else None
+            how = "render_frames (pipelined trajectory loop, minimal apron), 1 warm-up frame"
+        else:
+            sdist.render_frame_tile_parallel(R, sel[0], hw, ns, mode="fused")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(frames):
+                last = sdist.render_frame_tile_parallel(R, sel[k + 1], hw, ns, mode="fused")
+            torch.cuda.synchronize()
+            ms = 1000.0 * (time.perf_counter() - t0) / frames
+            field_ms = field_frac = None
+            how = "dist.render_frame_tile_parallel with ONE band (the 8-GPU path of config 5 on one GPU), reference apron, 1 warm-up frame"
+        pose = sel[-1]
+        tiles_all, nh, nw = tile_grid([hw[0] + 30, hw[1] + 30], 30)
+        pick = (nh // 2, nw // 2)
+        t_cpu = time.time()
+        ref = FR.render_frame_tiled(weights, lut, vox, (pose[0].numpy(), pose[1].numpy(), pose[2].numpy(), pose[3]), hw, ns, z, genc,
+                                    tiles=[pick])
+        r0, c0, tile = ref[pick]
+        err = float((last[:, :, r0:r0 + tile.shape[2], c0:c0 + tile.shape[3]].cpu() - tile).abs().max())
+        recs.append({"baseline_config": cfg, "workload": f"{hw[1]}x{hw[0]}, num_samples={ns}, scene_size={args.scene_size}", "frames": frames,
+                     "ms_per_frame": ms, "frames_per_s": 1000.0 / ms, "field_kernel_ms": field_ms, "field_frac": field_frac, "how": how,
+                     "max_abs_err_tile": err, "tile": f"{pick} of the reference's {nh}x{nw} tile grid vs the CPU oracle "
+                                                      f"({time.time() - t_cpu:.1f} s of CPU incl. the frame-wide ray casting / sky pre-pass)",
+                     "precision_gates": {"cnn": R.cnn_calibration, "field": {k: v for k, v in (R.field_gate or {}).items() if k != "measurements"}}})
+    return recs
+
+
+def rvip_roofline(R, poses, hw):
+    """SURVEY 8(d) record of the ray marcher: algorithmic bytes = 4 B x DDA steps of the reference's cell-by-cell loop
+    (ray_voxel_intersection.cu:115-229; counted by the measurement build of the same kernel, sdn_rvip_debug_counts, WITHOUT the
+    occupancy grid) + 84 B per ray of output, over the kernel's duration (HIP events on the launch stream, product kernel with
+    empty-space skipping), against the HBM peak.  Latency / divergence bound: the fraction is small by construction."""
+    from scenedreamer_amd import ops
+    from scenedreamer_amd.camera import frame_intrinsics
+    sel = list(poses)[:6]
+    steps = reads = jumps = rays = 0
+    ms = []
+    with torch.no_grad():
+        for pose in sel:
+            f, c, cam_res = frame_intrinsics(pose[3], hw, R.pad)
+            ref = ops.rvip_step_counts(R.volume, pose[0], pose[1], pose[2], f, c, cam_res, R.M, accelerate=False, palette=R.palette)
+            got = ops.rvip_step_counts(R.volume, pose[0], pose[1], pose[2], f, c, cam_res, R.M, accelerate=True, palette=R.palette)
+            steps += ref["iterations"]; reads += got["volume_reads"]; jumps += got["block_jumps"]; rays += ref["rays"]
+            R.cast_rays(pose, hw)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            R.cast_rays(pose, hw)
+            b.record()
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b))
+    k = len(sel)
+    alg = (4.0 * steps + 84.0 * rays) / k
+    t = float(np.mean(ms))
+    return {"bound": "hbm", "kernel": "rvip_kernel (exact DDA + exact empty-space skipping" + (", uint8 volume)" if R.palette is not None else ", int32 volume)"),
+            "achieved": alg / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "traffic": None, "avg_launch_ms": t, "rays_per_launch": rays / k, "reference_dda_steps_per_launch": steps / k,
+            "reference_dda_steps_per_ray": steps / max(1, rays), "algorithmic_bytes_per_launch": alg,
+            "volume_reads_per_launch_this_kernel": reads / k, "empty_block_jumps_per_launch": jumps / k,
+            "bytes_per_volume_read": 1 if R.palette is not None else 4,
+            "timing": f"HIP events around a stand-alone launch per pose ({k} poses of the timed region), outside the timed region",
+            "note": "algorithmic = 4 B x the reference's DDA steps + 84 B/ray (SURVEY 8d); this kernel skips empty 8x16x16 blocks and, on "
+                    "the compact volume, reads 1 B per visited cell, so it moves far fewer bytes than that; the walk is latency / "
+                    "divergence bound, not bandwidth bound"}
+
+
+def sustained_ceiling(roof):
+    """roofline.peak_sustained: what the part sustains on the field MLP's own instruction mix, measured IN THIS RUN by the
+    micro-kernel tools/mlp_shape_ubench (one 256 -> 256 layer in the kernel's shape: 4 waves / CU, 32 samples per wave,
+    v_mfma_f32_32x32x16_f16 3-term split on random f16 operands, fragments from the LDS ring): with ONLY the MFMAs and their
+    fragment reads in the loop it is the ceiling of any schedule of this arithmetic (the part lowers its clock under this load);
+    `frac_of_sustained` divides the kernel's achieved rate by that ceiling scaled to the kernel's instruction mix."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "mlp_shape_ubench")
+    if not os.path.exists(exe):
+        roof["peak_sustained"] = {"skipped": "tools/mlp_shape_ubench is not built (python -c 'import __graft_entry__ as g; g.build()')"}
+        return
+    r = subprocess.run([exe, "--ceiling"], capture_output=True, text=True, timeout=120)
+    line = next((ln for ln in r.stdout.splitlines() if ln.startswith("{")), None)
+    if r.returncode != 0 or line is None:
+        roof["peak_sustained"] = {"skipped": f"micro-kernel failed (rc {r.returncode}): {r.stderr[-300:]}"}
+        return
+    u = json.loads(line)
+    issued = roof.get("issued_over_algorithmic") or 3.0
+    ceil3 = u["mfma_and_fragment_reads_only"]["tflops_algorithmic_3term"]
+    mix = ceil3 * 3.0 / issued
+    roof["peak_sustained"] = {"value": mix, "unit": "TFLOP/s algorithmic", "three_term_layer": ceil3, "micro_kernel": u,
+                              "note": "ceiling for THIS kernel's mix = 3-term ceiling x 3 / issued_over_algorithmic (the fp6-corrected colour "
+                                      "layers issue fewer MFMA slots per product); nominal peak 2500 TFLOP/s is what `frac` divides by"}
+    roof["frac_of_sustained"] = roof["achieved"] / mix
+
+
 def _single_kernel(R):
     from scenedreamer_amd import fused
     return fused.single_kernel(R) and fused.precision_profile(R)[0] != 2
@@ -223,15 +436,34 @@ def fused_eps(R):
     return fused.precision_profile(R)[1]
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write(f"[bench] --gpus {args.gpus} without WORLD_SIZE: re-executing under torch.distributed.run on port {port}\n")
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run "
+                         f"`python bench.py --gpus {args.gpus}` without a launcher)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     ndev = torch.cuda.device_count()
-    if local >= ndev and args.backend == "nccl":
-        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPU(s) visible (RCCL needs one GPU per rank; --backend gloo shares GPUs)")
+    if world > ndev and args.backend == "nccl":
+        raise SystemExit(f"rank {rank}: {world} ranks but only {ndev} GPU(s) visible (RCCL needs one GPU per rank; --backend gloo shares GPUs)")
     torch.cuda.set_device(local % ndev)
     dev = torch.device("cuda", local % ndev)
     if world > 1:
@@ -283,6 +515,14 @@ def main():
         frame_pose = lambda k: poses[order[sdist.shard_frames(range(k * world, (k + 1) * world), rank, world)[0] % len(order)]]
     hw = (args.height, args.width)
     setup_s = time.time() - t_setup
+    if args.only:       # just one of the extra records (one GPU)
+        assert world == 1, "--only runs on one GPU"
+        if args.only == "dropin":
+            print(json.dumps({"dropin": dropin_record(args, weights, scene, dev)}))
+        else:
+            R.render_frame(poses[0], hw, args.samples, mode=mode)      # (the style's precision gates, as the headline run has them)
+            print(json.dumps({"other_configs": other_configs(args, R, weights, scene, poses, dev)}))
+        return
 
     def barrier():
         if world > 1:
@@ -342,9 +582,13 @@ def main():
     pinned = [torch.empty((hw[0], hw[1], 3), dtype=torch.uint8).pin_memory() for _ in range(2)]
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    for k in range(n_del):
-        im = R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=args.apron)
-        pinned[k & 1].copy_(to_uint8_hwc(im), non_blocking=True)
+    if n_del and pipelined:     # the path that is timed above (render_frames), every frame converted and copied to pinned host memory
+        for k, im in enumerate(R.render_frames([frame_pose(args.warmup + k) for k in range(n_del)], hw, args.samples, mode=mode, apron=args.apron)):
+            pinned[k & 1].copy_(to_uint8_hwc(im), non_blocking=True)
+    else:
+        for k in range(n_del):
+            im = R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=args.apron)
+            pinned[k & 1].copy_(to_uint8_hwc(im), non_blocking=True)
     torch.cuda.synchronize()
     delivered_fps = n_del / (time.perf_counter() - t2) if n_del else None
 
@@ -417,6 +661,11 @@ def main():
                 + f" alone on the whole padded frame ({alone[0]['samples_per_launch']} samples), outside the timed region")
     else:
         roof, roof_grid = R.measure_roofline(frame_pose(args.warmup), hw, args.samples, mode)
+    roof_rvip = None
+    if rank == 0 and not tile_parallel:
+        roof_rvip = rvip_roofline(R, timed_poses, hw)
+        if roof is not None and roof.get("bound") == "mfma" and not args.profile:
+            sustained_ceiling(roof)
 
     if rank == 0:
         fps = (1 if tile_parallel else world) * args.steps / elapsed
@@ -447,8 +696,11 @@ def main():
                                      "pixel -- the image is bit-identical (tests/test_render_gpu.py, test_fullsize_gpu.py)"},
             "frame_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "delivered_frames_per_s_uint8_host": delivered_fps,
             "stage_ms": stage_ms, "setup_s": setup_s, "broadcast": bstats or None, f"ms_per_step_apron_{other}": other_ms,
-            "roofline": roof, "roofline_grid_sampler": roof_grid, "roofline_cnn": roof_cnn,
+            "roofline": roof, "roofline_grid_sampler": roof_grid, "roofline_cnn": roof_cnn, "roofline_rvip": roof_rvip,
         }
+        gates = {"cnn": getattr(R, "cnn_calibration", None),
+                 "field": {k: v for k, v in (getattr(R, "field_gate", None) or {}).items() if k != "measurements"} or None,
+                 "colour_terms": (getattr(R, "field_gate", None) or {}).get("colour")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, weights, scene, R.z.cpu().numpy(), R.global_enc.cpu().numpy())
             # a reduced-precision internal path is named (`dtype`) together with its MEASURED max-abs error:
@@ -464,11 +716,28 @@ def main():
             errs = {t: float(np.abs(gpu_img[:, :, r0:r0 + im.shape[2], c0:c0 + im.shape[3]] - im.numpy()).max())
                     for t, (r0, c0, im) in cpu_baseline.tiles.items()}
             out["precision"] = {"max_abs_err": max(errs.values()), "bound": 1e-3, "quantity": "image (tanh output, range [-1, 1])",
+                                "gates": gates,
                                 "per_tile": {f"{t[0]},{t[1]}": e for t, e in errs.items()},
                                 "where_measured": f"{len(errs)} tiles of the reference's tile grid ({sum(im.shape[2] * im.shape[3] for _, _, im in cpu_baseline.tiles.values())} "
                                                   f"of {hw[0] * hw[1]} pixels), pose 8 of the 40-pose orbit, this run's GPU path vs the fp32 CPU "
                                                   f"run named in cpu_baseline (kind: {out['cpu_baseline']['kind']}); one whole frame (40 of 40 "
                                                   "tiles) and configs 3 / 5 against the oracle: tests/test_config_parity_gpu.py"}
+        if "precision" not in out:
+            out["precision"] = {"gates": gates, "max_abs_err": None,
+                                "note": "per-style gates only: the error against the CPU run is measured with the cpu_baseline leg"}
+        if world == 1 and mode == "fused" and not tile_parallel:
+            if not args.no_other_configs and (hw, args.samples, args.scene_size) == ((540, 960), 24, 2048):
+                try:
+                    out["other_configs"] = other_configs(args, R, weights, scene, poses, dev)
+                except Exception as e:  # noqa: BLE001 -- an extra record must not cost the headline line
+                    out["other_configs"] = {"error": f"{type(e).__name__}: {e}"}
+            if not args.no_dropin:
+                del R
+                torch.cuda.empty_cache()
+                try:
+                    out["dropin"] = dropin_record(args, weights, scene, dev)
+                except Exception as e:  # noqa: BLE001
+                    out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist

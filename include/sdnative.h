@@ -79,6 +79,15 @@ int sdn_rvip_u8(const uint8_t *vox, const int32_t *palette256, const int64_t *di
                 float *out_raydirs, sdn_stream_t stream);
 int sdn_rvip_build_occupancy_u8(const uint8_t *vox, const int64_t *dims, const int64_t *strides, uint8_t *occupancy,
                                 sdn_stream_t stream);
+/* Measurement entry point (no reference counterpart; SURVEY 8(d): the ray marcher's algorithmic bytes are 4 B x DDA steps +
+ * 84 B per ray): the launch of sdn_rvip (palette256 == NULL, vox int32) or sdn_rvip_u8 (palette256 != NULL, vox uint8) with the
+ * walk's counters summed over all rays into counters dev u64[4], ZEROED by the caller: [0] loop iterations, [1] volume reads,
+ * [2] empty-block jumps, [3] rays.  With occupancy == NULL, [0] is the number of cell-by-cell DDA steps the reference's loop
+ * executes for this frame (ray_voxel_intersection.cu:115-229).  Outputs are written as by sdn_rvip. */
+int sdn_rvip_debug_counts(const void *vox, const int32_t *palette256, const int64_t *dims, const int64_t *strides,
+                          const float *cam_ori, const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
+                          const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id, float *out_depth,
+                          float *out_raydirs, uint64_t *counters, sdn_stream_t stream);
 /* int32 ids (any strides) -> palette indices, out dev u8 [dims] contiguous.  id2idx dev u8[n_ids]: index of every id
  * (id2idx[0] == 0); *bad_flag (dev int32, zeroed by the caller) is set when the volume holds an id outside the table
  * or one the palette does not contain. */

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "sdn_rvip_build_occupancy": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_rvip_u8": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "sdn_rvip_build_occupancy_u8": (c_i, [c_p, c_p, c_p, c_p, c_p]),
+    "sdn_rvip_debug_counts": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "sdn_volume_compact": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p]),
     "sdn_scene_columns": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
     "sdn_scene_paste_trees": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),

@@ -1943,6 +1943,18 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 if (grp_done) break;
             }
         }
+        if constexpr (FUSED) {
+            // early termination dropped the group's remaining passes: their samples still take part in `is_gnd` (any sample of
+            // the ray at world x <= 1, scenedreamer.py:380-382), as they do in encode_kernel -- place them (no gathers, no MLP)
+            if (grp_hit && n_done < p.nch) {
+                RayBoxes rb;
+                float dd[3];
+                enc_load_ray(enc, rr, rb, dd);
+#pragma unroll 1
+                for (int c2 = n_done; c2 < p.nch; c2++)
+                    gnd = gnd || enc_place(enc, rb, dd, rl, c2 * SAMP_PER_STEP + (j & 3), ray_ok).gnd;
+            }
+        }
         if (p.passes && threadIdx.x == 0) p.passes[grp] = (uint8_t)n_done;   // passes this group went through (tests / bench)
 
         // ---- blend the sky, store ---------------------------------------------------------------------------------

@@ -47,6 +47,8 @@ struct RvipParams {
     const uint8_t *occ;   // [nb0][nb1][nb2] 1 = block holds a non-empty cell; nullptr = no skipping
     int32_t nb1, nb2;
     const int32_t *palette;   // uint8 volumes: block id of palette index i (palette[0] == 0); unused for int32 volumes
+    unsigned long long *counters;   // COUNT instantiation only (sdn_rvip_debug_counts): [0] loop iterations (cell steps + block jumps),
+                                    // [1] volume reads, [2] block jumps, [3] rays
 };
 
 constexpr int BS0 = 3, BS1 = 4, BS2 = 4;   // log2 of the occupancy block extent per axis (axis 0 is the short, vertical one)
@@ -97,7 +99,8 @@ __device__ __forceinline__ float first_crossing(int cell, float ori, float dir) 
     return HUGE_VALF;
 }
 
-template <typename V>
+// COUNT: the measurement build behind sdn_rvip_debug_counts -- the same walk, plus per-wave sums of its step counters
+template <typename V, bool COUNT = false>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__restrict__ out_id,
                                                                   float *__restrict__ out_depth,
                                                                   float *__restrict__ out_dirs,
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
     const int64_t depth_plane = (int64_t)p.H * p.W * p.M;
     const int64_t obase = pix * p.M;
     bool quit = false;
+    unsigned n_iter = 0, n_read = 0, n_jump = 0;
 #pragma unroll 1
     for (int cur = 0; cur < p.M; cur++) {
         float t = __builtin_nanf("0"), te = __builtin_nanf("0");
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
         while (!quit) {
             float tnow;
             bool skipped = false;
+            if constexpr (COUNT) n_iter++;
             if (p.occ && (unsigned)i0 < (unsigned)p.vd[0] && (unsigned)i1 < (unsigned)p.vd[1] &&
                 (unsigned)i2 < (unsigned)p.vd[2] &&
                 p.occ[((int64_t)(i0 >> BS0) * p.nb1 + (i1 >> BS1)) * p.nb2 + (i2 >> BS2)] == 0) {
@@ -196,6 +201,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
                 if (d1 != 0) t1 = ((float)(i1 + a1) - o1) / d1;
                 if (d2 != 0) t2 = ((float)(i2 + a2) - o2) / d2;
                 skipped = true;
+                if constexpr (COUNT) n_jump++;
             }
             // axis choice with the reference's <= tie-breaks (:143, :160, :175)
             if (skipped) {
@@ -220,6 +226,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
                 (unsigned)i2 >= (unsigned)p.vd[2])
                 continue;  // :198 outside the volume but heading towards it
             blk = vox[i0 * p.vs[0] + i1 * p.vs[1] + i2 * p.vs[2]];
+            if constexpr (COUNT) n_read++;
             if (blk == 0) continue;
             if constexpr (sizeof(V) == 1) blk = p.palette[blk];
             t = tnow;
@@ -229,6 +236,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void rvip_kernel(int32_t *__rest
         out_depth[obase + cur] = t;
         out_depth[depth_plane + obase + cur] = te;
         out_id[obase + cur] = blk;
+    }
+    if constexpr (COUNT) {
+        atomicAdd(p.counters + 0, (unsigned long long)n_iter);
+        atomicAdd(p.counters + 1, (unsigned long long)n_read);
+        atomicAdd(p.counters + 2, (unsigned long long)n_jump);
+        atomicAdd(p.counters + 3, 1ull);
     }
 }
 
@@ -285,7 +298,7 @@ template <typename V>
 static int rvip_launch(const V *vox, const int32_t *palette, const int64_t *dims, const int64_t *strides, const float *cam_ori,
                        const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
                        const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id,
-                       float *out_depth, float *out_raydirs, sdn_stream_t stream) {
+                       float *out_depth, float *out_raydirs, sdn_stream_t stream, unsigned long long *counters = nullptr) {
     SDN_REQUIRE(vox && dims && strides && cam_ori && cam_dir && cam_up && cam_c && img_dims,
                 "sdn_rvip: null argument");
     SDN_REQUIRE(out_voxel_id && out_depth && out_raydirs, "sdn_rvip: null output");
@@ -331,9 +344,14 @@ static int rvip_launch(const V *vox, const int32_t *palette, const int64_t *dims
     p.nb1 = (int32_t)sdn::div_up<int64_t>(dims[1], 1 << BS1);
     p.nb2 = (int32_t)sdn::div_up<int64_t>(dims[2], 1 << BS2);
 
+    p.counters = counters;
     const int n_wg = sdn::div_up(p.n_tiles, WAVES_PER_WG);
-    hipLaunchKernelGGL(rvip_kernel<V>, dim3(n_wg), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, out_voxel_id,
-                       out_depth, out_raydirs, vox, p);
+    if (counters)
+        hipLaunchKernelGGL((rvip_kernel<V, true>), dim3(n_wg), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, out_voxel_id, out_depth,
+                           out_raydirs, vox, p);
+    else
+        hipLaunchKernelGGL((rvip_kernel<V, false>), dim3(n_wg), dim3(64 * WAVES_PER_WG), 0, (hipStream_t)stream, out_voxel_id, out_depth,
+                           out_raydirs, vox, p);
     return sdn::check_launch("sdn_rvip");
 }
 
@@ -352,4 +370,20 @@ extern "C" int sdn_rvip_u8(const uint8_t *vox, const int32_t *palette256, const 
     SDN_REQUIRE(palette256, "sdn_rvip_u8: null palette");
     return rvip_launch<uint8_t>(vox, palette256, dims, strides, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples,
                                 occupancy, out_voxel_id, out_depth, out_raydirs, stream);
+}
+
+// Measurement entry point (the ray marcher's algorithmic bytes are 4 B x DDA steps + 84 B per ray): the same launch
+// as sdn_rvip / sdn_rvip_u8 (palette256 != NULL selects the uint8 volume) with the walk's counters summed over all rays into
+// counters dev u64[4], ZEROED by the caller: [0] loop iterations, [1] volume reads, [2] empty-block jumps, [3] rays.  Without an
+// occupancy grid [0] is the number of cell-by-cell DDA steps the reference's loop executes (ray_voxel_intersection.cu:115-229).
+extern "C" int sdn_rvip_debug_counts(const void *vox, const int32_t *palette256, const int64_t *dims, const int64_t *strides,
+                                     const float *cam_ori, const float *cam_dir, const float *cam_up, float cam_f, const float *cam_c,
+                                     const int *img_dims, int max_samples, const uint8_t *occupancy, int32_t *out_voxel_id,
+                                     float *out_depth, float *out_raydirs, uint64_t *counters, sdn_stream_t stream) {
+    SDN_REQUIRE(counters, "sdn_rvip_debug_counts: null counters");
+    if (palette256)
+        return rvip_launch<uint8_t>((const uint8_t *)vox, palette256, dims, strides, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims,
+                                    max_samples, occupancy, out_voxel_id, out_depth, out_raydirs, stream, (unsigned long long *)counters);
+    return rvip_launch<int32_t>((const int32_t *)vox, nullptr, dims, strides, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples,
+                                occupancy, out_voxel_id, out_depth, out_raydirs, stream, (unsigned long long *)counters);
 }

@@ -230,46 +230,32 @@ def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode=
 
 
 def agree_precision(renderer, pose, resolution_hw, num_samples, group=None):
-    """The renderer's per-style precision gates (Renderer.calibrate_field: colour layers fp6 / 3-term, fused field / fp32
-    fallback; Renderer.mfma_cnn: 1-term / 3-term 3x3 convolutions) evaluated ONCE FOR THE JOB: every rank renders the same
-    frame (`pose`; renders are bit-reproducible, so every rank measures the same differences), the measurements are reduced
-    with MAX, and every rank adopts the decisions that follow from the reduced values -- bands of one frame, or frames of one
-    trajectory, never mix precisions.  Gates whose setting is explicit are left alone.  Returns {"cnn": .., "field": ..}."""
-    import os
-    from . import renderer as rmod
-    explicit_cnn = getattr(renderer, "cnn_terms3x3", None) is not None or "SDN_CNN_TERMS" in os.environ
+    """The renderer's per-style precision gates (Renderer.calibrate_style: colour layers fp6 / 3-term, 3x3 convolutions 1-term /
+    3-term, fused path / fp32 fallback -- measured end to end against the fp32 frame) evaluated ONCE FOR THE JOB: every rank
+    calibrates on the same frame (`pose`; renders are bit-reproducible, so every rank measures the same errors), the
+    measurements are reduced with MAX, and every rank adopts the decisions that follow from the reduced values
+    (Renderer.adopt_precision) -- bands of one frame, or frames of one trajectory, never mix precisions.  Explicit settings
+    stay as they are.  Returns {"cnn": cnn_calibration, "field": field_gate}."""
     renderer.cnn_calibration = None
     renderer.field_gate = None
     renderer.colour_terms_auto = None
-    renderer.render_frame(pose, resolution_hw, num_samples, mode="fused")
-    cal = dict(renderer.cnn_calibration) if renderer.cnn_calibration else None
-    fg = dict(renderer.field_gate) if getattr(renderer, "field_gate", None) else None
+    meas = renderer.calibrate_style(pose, resolution_hw, num_samples)["measurements"]
     if _is_init() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
-        v = torch.tensor([cal["max_abs_diff_1term_vs_3term"] if cal else -1.0,
-                          fg["max_abs_err_vs_fp32"] if fg else -1.0,
-                          fg["colour"].get("max_abs_diff_fp6_vs_3term", -1.0) if fg else -1.0], dtype=torch.float64, device=renderer.dev)
+        slots = [("field_err", k) for k in sorted(meas["field_err"])] + [("image_err", k) for k in sorted(meas["image_err"])]
+        slots += [(k, None) for k in ("colour_diff", "cnn_diff") if k in meas]
+        v = torch.tensor([meas[a][b] if b is not None else meas[a] for a, b in slots], dtype=torch.float64, device=renderer.dev)
         all_reduce(v, op=dist.ReduceOp.MAX, group=group)
-        d_cnn, e_field, d_col = (float(x) for x in v.tolist())
-        if fg is not None:
-            if d_col >= 0:
-                fg["colour"]["max_abs_diff_fp6_vs_3term"] = d_col
-                fg["colour"]["terms"] = 6 if d_col <= fg["colour"]["bound"] else 3
-                renderer.colour_terms_auto = fg["colour"]["terms"]
-            fg["max_abs_err_vs_fp32"] = e_field
-            fg["path"] = "fused" if e_field <= fg["bound"] else "unfused"
-            fg["agreed_over_ranks"] = world
-            renderer.field_gate = fg
-        if cal is not None and not explicit_cnn:
-            cal["max_abs_diff_1term_vs_3term"] = d_cnn
-            charged = e_field if e_field >= 0 else cal["field_err_charged"]
-            cal["field_err_charged"] = charged
-            cal["terms3x3"] = 1 if (d_cnn <= cal["bound"] and charged + d_cnn <= cal["image_budget"]) else 3
-            cal["agreed_over_ranks"] = world
-    if cal is not None and not explicit_cnn:
-        cal["pixels"] = max(cal["pixels"], rmod.CNN_CAL_PIXELS)      # the job's decision is final: no further per-rank calibration
-        renderer.cnn_calibration = cal
-    return {"cnn": renderer.cnn_calibration, "field": getattr(renderer, "field_gate", None)}
+        for (a, b), x in zip(slots, v.tolist()):
+            if b is not None:
+                meas[a][b] = float(x)
+            else:
+                meas[a] = float(x)
+        renderer.adopt_precision(meas)
+        renderer.field_gate["agreed_over_ranks"] = world
+        if renderer.cnn_calibration is not None:
+            renderer.cnn_calibration["agreed_over_ranks"] = world
+    return {"cnn": renderer.cnn_calibration, "field": renderer.field_gate}
 
 
 def agree_cnn_precision(renderer, pose, resolution_hw, num_samples, group=None):

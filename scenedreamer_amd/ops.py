@@ -95,6 +95,28 @@ def ray_voxel_intersection_perspective(in_voxel, cam_ori, cam_dir, cam_up, cam_f
     return [voxel_id, depth2, raydirs]
 
 
+def rvip_step_counts(in_voxel, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples, accelerate=True, palette=None):
+    """Counters of the ray marcher's walk for one frame (sdn_rvip_debug_counts; measurement only): dict with `iterations`
+    (accelerate=False: the cell-by-cell DDA steps of the reference's loop), `volume_reads`, `block_jumps`, `rays`."""
+    H, W, M = int(img_dims[0]), int(img_dims[1]), int(max_samples)
+    dev = in_voxel.device
+    cam_f = float(np.asarray(cam_f, dtype=np.float64).reshape(-1)[0])
+    with torch.cuda.device(dev):
+        vid = torch.empty((H, W, M, 1), dtype=torch.int32, device=dev)
+        d2 = torch.empty((2, H, W, M, 1), dtype=torch.float32, device=dev)
+        rd = torch.empty((H, W, 1, 3), dtype=torch.float32, device=dev)
+        cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+        occ = voxel_occupancy(in_voxel) if accelerate else None
+        rc = capi.lib().sdn_rvip_debug_counts(in_voxel.data_ptr(), palette.data_ptr() if palette is not None else None,
+                                              _l3(*in_voxel.shape), _l3(*in_voxel.stride()), _host3(cam_ori, "cam_ori"),
+                                              _host3(cam_dir, "cam_dir"), _host3(cam_up, "cam_up"), cam_f,
+                                              _f2(float(cam_c[0]), float(cam_c[1])), _i2(H, W), M, occ.data_ptr() if occ is not None else None,
+                                              vid.data_ptr(), d2.data_ptr(), rd.data_ptr(), cnt.data_ptr(), _stream(in_voxel))
+    capi.check(rc, "sdn_rvip_debug_counts")
+    it, rd_, jp, rays = (int(v) for v in cnt.tolist())
+    return {"iterations": it, "volume_reads": rd_, "block_jumps": jp, "rays": rays}
+
+
 def sample_depth_batched(depth2, nsamples, deterministic=False, use_box_boundaries=True, sample_depth=4, rand=None,
                          division="reciprocal", boundary_rand=None):
     """mc_utils.sample_depth_batched (imaginaire/model_utils/gancraft/mc_utils.py:82-151), same signature, defaults and

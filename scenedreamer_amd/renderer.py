@@ -266,70 +266,118 @@ class Renderer:
         self.field_gate = None
         self.colour_terms_auto = None
 
-    # ------------------------------------------------------------------ per-style precision gates of the field
-    def calibrate_field(self, vid, d2, rd, cam_ori, sky_c, sky_avg, ns):
-        """Measure, for the CURRENT weights and style, what the reduced-precision choices of the fused field cost -- on up to
-        FIELD_CAL_RAYS rays of this frame that hit something -- and decide (the record is `field_gate`, bench.py prints it):
+    # ------------------------------------------------------------------ per-style precision gates
+    def calibrate_style(self, pose, resolution_hw, num_samples):
+        """Measure END TO END, for the CURRENT weights and style, what the reduced-precision choices of the fused path cost, and
+        decide.  One frame (`pose`; at most CAL_MAX_PIXELS pixels -- a larger frame is calibrated at a reduced resolution) is
+        rendered by the reference's op sequence in fp32 (field_unfused + render_cnn: PyTorch fp32 + the drop-in HIP ops -- the
+        path the CPU-oracle tests validate) and by the candidates; the cheapest candidate inside the bounds is adopted:
 
-          colour layers: fc_5 / fc_6 as f16 + MX-fp6 corrections (colour_terms 6) only if net_out differs from the 3-term
-            evaluation by at most COLOUR_AUTO_BOUND; else the 3-term split (colour_terms_auto = 3);
-          the fused field itself (3-term f16 split with f32 accumulation): against the fp32 evaluation of the same rays by the
-            reference's op sequence (field_unfused: PyTorch fp32 + the drop-in HIP ops).  Above FIELD_AUTO_BOUND the renderer
-            serves this style through the un-fused fp32 path (`path: "unfused"`): slow, but inside the tolerance.
+          colour layers fc_5 / fc_6: f16 + MX-fp6 corrections (colour_terms 6) if net_out stays within COLOUR_AUTO_BOUND of the
+            3-term evaluation, else the 3-term split;
+          the fused field (3-term f16 split, f32 accumulate): net_out against the fp32 net_out, bound FIELD_AUTO_BOUND -- above
+            it the style is served by the fp32 op sequence (`path: "unfused"`): slow, but inside the tolerance;
+          render CNN 3x3 layers: ONE f16 product if the image stays within CNN_AUTO_BOUND of the 3-term image AND its MEASURED
+            total error against the fp32 image (field error included) within IMAGE_AUTO_BOUND; else the 3-term split if THAT is
+            within IMAGE_AUTO_BOUND; else the fp32 path.
 
-        The error depends on the loaded weights (the density head amplifies hidden-activation error): gains 2-4x
-        larger than the synthetic set's move it across the bound (tests/test_precision_gates_gpu.py).  An explicit
-        colour_terms (set_precision / SDN_MLP_COLOUR_TERMS) bypasses the colour decision, not the measurement.
-        Returns the record, or None when no ray of the frame hits anything (the next frame calibrates)."""
+        The errors depend on the loaded weights (the density head amplifies hidden-activation error; 3x3 gains compound over
+        four layers): tests/test_precision_gates_gpu.py scales them until every gate closes.  Explicit settings (set_precision,
+        SDN_MLP_COLOUR_TERMS, SDN_CNN_TERMS) are measured but not overridden.  Costs one fp32 frame (~0.2 s at 960x540x24) per
+        style.  Records: `field_gate`, `cnn_calibration` (bench.py prints both)."""
         from . import fused
+        H, W = resolution_hw
+        if H * W > CAL_MAX_PIXELS:
+            f = (CAL_MAX_PIXELS / float(H * W)) ** 0.5
+            H, W = max(8, int(H * f)), max(8, int(W * f))
+        crop = self.pad // 2
         with torch.no_grad():
-            hit = (vid[:, 0] != 0).nonzero().reshape(-1)
-            if hit.numel() == 0:
-                return None
-            sel = hit[::max(1, hit.numel() // FIELD_CAL_RAYS)][:FIELD_CAL_RAYS]
-            sv, sd, sr, ss = vid[sel].contiguous(), d2[:, sel].contiguous(), rd[sel].contiguous(), sky_c[sel].contiguous()
-            ori = torch.as_tensor(cam_ori, dtype=torch.float32).reshape(3)
-            savg = torch.as_tensor(sky_avg).to(self.dev).reshape(1, 64)
-            ref = self.field_unfused(sv, sd, sr, ori.to(self.dev), ss, savg, ns)
-            explicit = getattr(self, "colour_terms", None)
-            if explicit is None and "SDN_MLP_COLOUR_TERMS" in os.environ:
-                explicit = int(os.environ["SDN_MLP_COLOUR_TERMS"])
+            vid, d2, rd, (H0, W0) = self.cast_rays(pose, (H, W))
+            n = H0 * W0
+            vid, d2, rd = vid.view(n, self.M), d2.view(2, n, self.M), rd.view(n, 3)
+            ori = torch.as_tensor(pose[0], dtype=torch.float32).reshape(3)
+            inner = (lambda im: im[:, :, crop:-crop, crop:-crop]) if crop else (lambda im: im)
+            # ---- the fp32 frame
+            sky32 = self.sky_features(rd)
+            savg32 = sky32.mean(dim=0, keepdim=True)
+            ori_dev = ori.to(self.dev)
+            ref_no = torch.cat([self.field_unfused(vid[r:r + CAL_CHUNK], d2[:, r:r + CAL_CHUNK], rd[r:r + CAL_CHUNK], ori_dev,
+                                                   sky32[r:r + CAL_CHUNK], savg32, num_samples) for r in range(0, n, CAL_CHUNK)], dim=0)
+            ref_img = inner(self.render_cnn(ref_no.view(1, H0, W0, 64)))
+            # ---- the fused field
+            sky_c, sky_avg = fused.sky_fused(self, rd)
+            explicit_ct = getattr(self, "colour_terms", None)
+            if explicit_ct is None and "SDN_MLP_COLOUR_TERMS" in os.environ:
+                explicit_ct = int(os.environ["SDN_MLP_COLOUR_TERMS"])
             saved = getattr(self, "colour_terms", None)
-            out = {}
+            no = {}
             try:
-                for ct in ((explicit,) if explicit is not None else (6, 3)):
+                for ct in ((explicit_ct,) if explicit_ct is not None else (6, 3)):
                     self.colour_terms = ct
-                    out[ct] = fused.field_fused(self, sv, sd, sr, ori.cpu(), ss, savg, ns)
+                    no[ct] = fused.field_fused(self, vid, d2, rd, ori, sky_c, sky_avg, num_samples)
             finally:
                 self.colour_terms = saved
-            rec = {"rays": int(sel.numel()), "samples_per_ray": int(ns)}
-            if explicit is not None:
-                ct = explicit
-                rec["colour"] = {"terms": ct, "set_explicitly": True}
-            else:
-                d63 = float((out[6] - out[3]).abs().max())
-                ct = 6 if d63 <= COLOUR_AUTO_BOUND else 3
-                rec["colour"] = {"terms": ct, "max_abs_diff_fp6_vs_3term": d63, "bound": COLOUR_AUTO_BOUND}
-            err = float((out[ct] - ref).abs().max())
-            rec.update(path="fused" if err <= FIELD_AUTO_BOUND else "unfused", max_abs_err_vs_fp32=err, bound=FIELD_AUTO_BOUND,
-                       quantity="net_out (per-ray feature, range [-1, 1])")
-        self.colour_terms_auto = ct if explicit is None else None
-        self.field_gate = rec
-        return rec
+            meas = {"field_err": {ct: float((v - ref_no).abs().max()) for ct, v in no.items()}}
+            if explicit_ct is None:
+                meas["colour_diff"] = float((no[6] - no[3]).abs().max())
+            ct = explicit_ct if explicit_ct is not None else (6 if meas["colour_diff"] <= COLOUR_AUTO_BOUND else 3)
+            # ---- the render CNN on the chosen field's output
+            explicit_t = getattr(self, "cnn_terms3x3", None)
+            if explicit_t is None and "SDN_CNN_TERMS" in os.environ:
+                explicit_t = int(os.environ["SDN_CNN_TERMS"])
+            x = no[ct].view(1, H0, W0, 64)
+            imgs = {t: inner(self._cnn_form(t)(x)).clone() for t in ((explicit_t,) if explicit_t is not None else (1, 3))}
+            meas["image_err"] = {t: float((im - ref_img).abs().max()) for t, im in imgs.items()}
+            if explicit_t is None:
+                meas["cnn_diff"] = float((imgs[1] - imgs[3]).abs().max())
+        meas.update(explicit_colour=explicit_ct, explicit_cnn=explicit_t, pixels=int(H * W), rays=int(n), samples_per_ray=int(num_samples),
+                    frame=f"{W}x{H} (+{self.pad}-px apron), {num_samples} samples/ray")
+        return self.adopt_precision(meas)
 
-    def _calibrate_on_pose(self, pose, resolution_hw, num_samples):
-        """calibrate_field on the rays of one pose (the trajectory loop calls it before it starts pipelining)."""
-        from . import fused
-        with torch.no_grad():
-            vid, d2, rd, cam_res = self.cast_rays(pose, resolution_hw)
-            n = cam_res[0] * cam_res[1]
-            vid, d2, rd = vid.view(n, self.M), d2.view(2, n, self.M), rd.view(n, 3)
-            sky_c, sky_avg = fused.sky_fused(self, rd)
-            return self.calibrate_field(vid, d2, rd, pose[0], sky_c, sky_avg, num_samples)
+    def adopt_precision(self, meas):
+        """Decisions that follow from calibrate_style's measurements (a pure function of `meas`: dist.agree_precision reduces the
+        measurements over the ranks with MAX and lets every rank adopt the same ones)."""
+        ect, et = meas["explicit_colour"], meas["explicit_cnn"]
+        ct = ect if ect is not None else (6 if meas["colour_diff"] <= COLOUR_AUTO_BOUND else 3)
+        ferr = meas["field_err"][ct]
+        path = "fused" if ferr <= FIELD_AUTO_BOUND else "unfused"
+        bound = float(getattr(self, "cnn_auto_bound", None) or CNN_AUTO_BOUND)
+        ierr = meas["image_err"]
+        cal = None
+        if et is None:
+            if meas["cnn_diff"] <= bound and ierr[1] <= IMAGE_AUTO_BOUND:
+                t = 1
+            else:
+                t = 3
+                if ierr[3] > IMAGE_AUTO_BOUND:
+                    path = "unfused"
+            cal = {"terms3x3": t, "max_abs_diff_1term_vs_3term": meas["cnn_diff"], "bound": bound,
+                   "image_err_vs_fp32": {"1-term": ierr[1], "3-term": ierr[3]}, "image_bound": IMAGE_AUTO_BOUND,
+                   "pixels": max(meas["pixels"], CNN_CAL_PIXELS), "calls": 1, "frame": meas["frame"], "measured": "end to end (calibrate_style)"}
+        self.field_gate = {
+            "path": path, "max_abs_err_vs_fp32": ferr, "bound": FIELD_AUTO_BOUND, "quantity": "net_out (per-ray feature, range [-1, 1])",
+            "colour": ({"terms": ct, "set_explicitly": True} if ect is not None else
+                       {"terms": ct, "max_abs_diff_fp6_vs_3term": meas["colour_diff"], "bound": COLOUR_AUTO_BOUND}),
+            "image_err_vs_fp32": ierr[et if et is not None else cal["terms3x3"]], "image_bound": IMAGE_AUTO_BOUND,
+            "rays": meas["rays"], "samples_per_ray": meas["samples_per_ray"], "frame": meas["frame"], "measurements": meas}
+        self.colour_terms_auto = ct if ect is None else None
+        if cal is not None:
+            self.cnn_calibration = cal
+            cache = self.__dict__.setdefault("_mfma_cnns", {})
+            if (4 - cal["terms3x3"]) in cache:
+                cache[4 - cal["terms3x3"]]._planes.clear()      # the form not chosen keeps its packed weights, not its planes
+        return self.field_gate
 
     def field_falls_back(self):
         g = getattr(self, "field_gate", None)
         return bool(g) and g.get("path") == "unfused"
+
+    def _cnn_form(self, terms3x3):
+        from .cnn import MfmaCNN
+        cache = self.__dict__.setdefault("_mfma_cnns", {})
+        if terms3x3 not in cache:
+            cache[terms3x3] = MfmaCNN(self, terms3x3)
+        return cache[terms3x3]
 
     def mfma_cnn(self, net_out):
         """The MFMA render CNN (cnn.MfmaCNN) for the current precision profile.
@@ -342,13 +390,8 @@ class Renderer:
         from the 3-term image by at most CNN_AUTO_BOUND (max abs) on that frame; otherwise the 3-term kernels are.
         The decision and the measured difference are kept in `cnn_calibration` (bench.py prints them).  An explicit
         cnn_terms3x3 (set_precision, or SDN_CNN_TERMS in the environment) bypasses the gate."""
-        from .cnn import MfmaCNN
         cache = self.__dict__.setdefault("_mfma_cnns", {})
-
-        def get(t):
-            if t not in cache:
-                cache[t] = MfmaCNN(self, t)
-            return cache[t]
+        get = self._cnn_form
 
         want = getattr(self, "cnn_terms3x3", None)
         if want is None and "SDN_CNN_TERMS" in os.environ:
@@ -505,7 +548,7 @@ class Renderer:
                 if field_kernel else "mlp_kernel")
         mlp = {"bound": "mfma", "kernel": f"{name} (f16 MFMA, 3-term split, colour layers {colour}, f32 accumulate)",
                "achieved": ach_m, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach_m / mfma_peak_tflops,
-               "traffic": traffic.get("mlp_kernel"), "traffic_source": traffic_src,
+               "traffic": traffic.get("field_kernel (mlp_kernel<0, 6, 1>)" if field_kernel else "mlp_kernel"), "traffic_source": traffic_src,
                "samples_per_launch": B, "samples_evaluated": n_eval, "algorithmic_flop_per_sample": 754176,
                "avg_launch_ms": ms_mlp, "ray_hit_fraction": hit, "group_hit_fraction": ev["group_hit_fraction"],
                "early_termination_eps": eps, "passes_skipped_by_termination": ev["passes_skipped_by_termination"],
@@ -612,9 +655,11 @@ class Renderer:
             if mode == "fused":
                 # per-style precision gates of the field (once per style; a host synchronisation on the style's first frame)
                 if getattr(self, "field_gate", None) is None and FIELD_GATE:
-                    self.calibrate_field(vid, d2, rd, cam_ori, sky_c, sky_avg, num_samples)
-                if self.field_falls_back():      # this style / these weights are outside the fused field's tolerance: fp32 op sequence
-                    mode, cam_ori = "unfused", cam_ori.to(self.dev)
+                    self.calibrate_style(pose, resolution_hw, num_samples)
+                if self.field_falls_back():      # this style / these weights are outside the fused path's tolerance: the fp32 op
+                    mode, cam_ori = "unfused", cam_ori.to(self.dev)       # sequence, all of it (sky MLP and CNN included)
+                    sky_c = self.sky_features(rd)
+                    sky_avg = sky_c.mean(dim=0, keepdim=True)
                     if cnn_mode is None:
                         cnn_mode = "torch"
             crop = self.pad // 2
@@ -675,7 +720,7 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
         side = self._side_stream = torch.cuda.Stream(self.dev)
     if mode == "fused":
         if getattr(self, "field_gate", None) is None and FIELD_GATE:
-            self._calibrate_on_pose(poses[0], resolution_hw, num_samples)
+            self.calibrate_style(poses[0], resolution_hw, num_samples)
         if self.field_falls_back():
             mode = "unfused"
     f0, c0, cam_res = frame_intrinsics(poses[0][3], resolution_hw, self.pad)
@@ -769,15 +814,18 @@ CNN_AUTO_BOUND = 5e-4   # mfma_cnn: largest image difference (max abs) at which 
 CNN_CAL_PIXELS = 400_000   # ... measured on every net_out of a style until this many pixels have been compared
 IMAGE_BUDGET = 8e-4        # ... and only while (field error charged) + (that difference) stays below this (north star: 1e-3)
 FIELD_NOMINAL_ERR = 2e-4   # field error charged to the budget when no field_gate was measured (goldens: 1.0 - 1.6e-4)
-COLOUR_AUTO_BOUND = 1e-4   # calibrate_field: largest net_out difference fp6-corrected vs 3-term colour layers (goldens: 4e-5)
-FIELD_AUTO_BOUND = 4e-4    # calibrate_field: largest net_out error of the fused field vs the fp32 op sequence
-FIELD_CAL_RAYS = 8192      # ... measured on this many rays (with a hit) of the style's first frame
+# calibrate_style (the renderer's end-to-end gates; the north star's tolerance is 1e-3 abs on radiance and on the image):
+COLOUR_AUTO_BOUND = 1e-4   # largest net_out difference fp6-corrected vs 3-term colour layers (goldens: 4e-5)
+FIELD_AUTO_BOUND = 8e-4    # largest net_out error of the fused field vs the fp32 op sequence, whole frame
+IMAGE_AUTO_BOUND = 8e-4    # largest image error of the whole fused path vs the fp32 path, whole frame
+CAL_MAX_PIXELS = 1 << 20   # frames above this many pixels are calibrated at a reduced resolution (same pose)
+CAL_CHUNK = 1 << 16        # rays per launch group of the fp32 field
 FIELD_GATE = os.environ.get("SDN_FIELD_GATE", "1") != "0"   # (0: no field calibration -- kernel timing experiments only)
 CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (conv2a, conv2b, conv3a, conv3b)
 
 
 L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md: 4 MiB per XCD, ~34.5 TB/s aggregate
-PMC_PROFILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
+PMC_PROFILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
 
 
 def _profiled_traffic():

@@ -157,7 +157,10 @@ def test_field_render_aux_outputs_and_device_camera(weights_full, scene256):
                                                sample_depth=R.sample_depth)
         depth = depth.view(n, ns)
         depth = torch.where(torch.isnan(depth) | torch.isinf(depth), torch.zeros_like(depth), depth)
-    assert torch.equal(host, dev) and torch.equal(host, with_aux)
+    assert torch.equal(host, dev)
+    # (the instantiation that also stores the weights is another compilation of the same arithmetic: hipcc contracts
+    # w * rgb + acc into an fma or not depending on the other uses of w -- not the same bits, the same value to an ulp)
+    assert float((host - with_aux).abs().max()) < 2e-6
     w, dp = aux["weights"], aux["depth"]
     assert tuple(w.shape) == tuple(dp.shape) == (n, ns)
     hit = vid[:, 0] != 0

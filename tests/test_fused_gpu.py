@@ -448,3 +448,34 @@ def test_single_kernel_field_equals_the_two_kernel_field(renderer):
         finally:
             renderer.field_single_kernel = None
             renderer.set_precision()
+
+
+def test_early_termination_single_kernel_equals_two_kernel(renderer):
+    """term_eps > 0 (wavefront-ballot early ray termination): the single-kernel field finishes `is_gnd` over the passes it
+    skips (placement only), so it still chooses the same sky term as encode_kernel -> mlp_kernel, which knows all samples up
+    front -- same bits, same pass counts; and net_out moves by at most 2 * term_eps against the untruncated evaluation."""
+    from scenedreamer_amd import fused
+    pose, vid, d2, rd, H0, W0 = _frame(renderer)
+    ori = torch.as_tensor(pose[0], dtype=torch.float32)
+    n = vid.shape[0]
+    with torch.no_grad():
+        sky_c, sky_avg = fused.sky_fused(renderer, rd)
+        try:
+            renderer.set_precision()
+            full = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, 24)
+            # an opaque variant of the density head, so that rays do terminate on the synthetic weights
+            for eps in (1e-3, 0.3):
+                outs = {}
+                for one in (False, True):
+                    renderer.set_precision(term_eps=eps)
+                    renderer.field_single_kernel = one
+                    pa = torch.zeros((n + 31) // 32, dtype=torch.uint8, device="cuda")
+                    outs[one] = (fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, 24, passes=pa), pa)
+                assert torch.equal(outs[False][1], outs[True][1]) and torch.equal(outs[False][0], outs[True][0]), eps
+                skipped = int((outs[True][1] < 6).sum()) - int((outs[True][1] == 0).sum())
+                d = float((outs[True][0] - full).abs().max())
+                print(f"term_eps {eps}: {skipped} of {int((outs[True][1] > 0).sum())} visited groups stopped early; max |net_out - untruncated| {d:.2e}")
+                assert d <= 2 * eps + 1e-6
+        finally:
+            renderer.field_single_kernel = None
+            renderer.set_precision()

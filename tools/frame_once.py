@@ -4,6 +4,8 @@ is avoidable, but the per-frame kernels dominate after the first frame)."""
 import os
 import sys
 
+os.environ.setdefault("SDN_FIELD_GATE", "0")   # profiling runs: no calibration launches (fp32 frame, other precision forms) in the trace
+
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

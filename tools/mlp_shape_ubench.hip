@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <string>
 #include <vector>
 #include <utility>
 
@@ -284,6 +285,8 @@ __global__ __launch_bounds__(512, 2) void shapeB(float *out, const half8 *in, co
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+static double g_last_us = 0.0, g_last_ghz = 0.0;   // (of the last run(): for --ceiling's JSON line)
+
 template <typename K>
 static void run(const char *name, K kernel, int threads, float *out, half8 *in, char *w) {
     const int layers = 600;
@@ -305,12 +308,15 @@ static void run(const char *name, K kernel, int threads, float *out, half8 *in, 
     float cyc = 0.f;
     if (threads == 256) hipMemcpy(&cyc, out + 256 * 256, 4, hipMemcpyDeviceToHost);
     if (threads == 256) printf("    %.0f shader cycles per layer (12288 = matrix pipe alone) -> %.2f GHz held\n", cyc, cyc / us_layer * 1e-3);
+    g_last_us = us_layer;
+    g_last_ghz = threads == 256 ? cyc / us_layer * 1e-3 : 0.0;
     // 128 samples per CU and layer; 2 * 256 * 256 FLOP per sample and layer (algorithmic), x3 issued
     printf("%-34s %8.3f us per layer  -> %6.1f TFLOP/s algorithmic on 256 CUs (%5.1f %% of 12288 cycles @2.4 GHz)\n", name, us_layer,
            128.0 * 2 * 256 * 256 * 256 / us_layer * 1e-6, 100.0 * 12288 / 2.4e3 / us_layer);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool ceiling = argc > 1 && std::string(argv[1]) == "--ceiling";   // bench.py: two runs + ONE JSON line
     float *out; half8 *in; char *w;
     hipMalloc(&out, 256 * 512 * 4);
     hipMalloc(&in, 64 * 32 * 16);
@@ -322,6 +328,17 @@ int main() {
         for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (unsigned short)(0x3000u | ((x >> 16) & 0x0fffu) | ((x >> 3) & 0x8000u)); }
         hipMemcpy(w, h.data(), h.size() * 2, hipMemcpyHostToDevice);
         hipMemcpy(in, h.data(), 64 * 32 * 16, hipMemcpyHostToDevice);
+    }
+    if (ceiling) {
+        auto tf = [](double us) { return 128.0 * 2 * 256 * 256 * 256 / us * 1e-6; };   // algorithmic TFLOP/s on 256 CUs (product counted once)
+        run("A MFMA + fragment reads only", shapeA<7>, 256, out, in, w);
+        const double us0 = g_last_us, ghz0 = g_last_ghz;
+        run("A 4 waves x 32 samples, 32x32x16", shapeA<0>, 256, out, in, w);
+        printf("{\"mfma_and_fragment_reads_only\": {\"us_per_layer\": %.4f, \"tflops_algorithmic_3term\": %.2f, \"clock_ghz_held\": %.3f}, "
+               "\"whole_layer_loop\": {\"us_per_layer\": %.4f, \"tflops_algorithmic_3term\": %.2f, \"clock_ghz_held\": %.3f}, "
+               "\"operands\": \"random f16 bit patterns (zeros clock higher)\", \"layer\": \"256 -> 256, 3-term f16 split, 128 samples per CU\", "
+               "\"matrix_pipe_cycles_per_layer\": 12288}\n", us0, tf(us0), ghz0, g_last_us, tf(g_last_us), g_last_ghz);
+        return 0;
     }
     run("A 4 waves x 32 samples, 32x32x16", shapeA<0>, 256, out, in, w);
     run("B 8 waves x 16 samples, 16x16x32", shapeB<0>, 512, out, in, w);
