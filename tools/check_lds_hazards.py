@@ -40,15 +40,21 @@ def regs_of(text):
     return out
 
 
-def run_block(lines, queue, problems):
+def run_block(lines, queue, problems, linear=False):
     """Replay one basic block from the pending-read queue `queue` (list of (frozenset of registers, line)); returns the
-    queue at its end.  Hazards are appended to `problems` (a dict keyed by line, so a line is reported once)."""
+    queue at its end.  Hazards are appended to `problems` (a dict keyed by line, so a line is reported once).
+    linear: `lines` is a whole kernel in text order -- what follows an unconditional branch is not reached by falling through
+    (it is a cold block entered by a jump, e.g. the placement-only tail of early ray termination), so the reads pending at the
+    branch do not carry into it; such blocks only hold compiler-generated LDS reads, which the compiler waits for itself."""
     queue = list(queue)
     for ln, raw in lines:
         line = raw.split(";")[0].strip()
         if not line or line.endswith(":") or line.startswith("."):
             continue
         op, _, rest = line.partition(" ")
+        if linear and op in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            queue = []
+            continue
         if op == "s_waitcnt":
             m = re.search(r"lgkmcnt\((\d+)\)", rest)
             if m:
@@ -84,7 +90,7 @@ def check_kernel(name, lines):
     control-flow graph (hipcc rotates its k loop, text order is not execution order)."""
     if not name.startswith("conv_kernel"):
         problems = {}
-        run_block(lines, [], problems)
+        run_block(lines, [], problems, linear=True)
         n = sum(1 for _, raw in lines if raw.split(";")[0].strip().startswith(("ds_read", "ds_load")))
         return n, [(ln, raw, why) for (ln, why), raw in sorted(problems.items())]
     return check_kernel_cfg(name, lines)
