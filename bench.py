@@ -418,7 +418,9 @@ def sustained_ceiling(roof):
         return
     u = json.loads(line)
     issued = roof.get("issued_over_algorithmic") or 3.0
-    ceil3 = u["mfma_and_fragment_reads_only"]["tflops_algorithmic_3term"]
+    # the higher of the two loops: with ONLY MFMAs + fragment reads the part draws more power and clocks lower (1.4 - 1.5 GHz) than with
+    # the activation work interleaved (2.0 - 2.2 GHz), so on some boxes the complete layer loop is the faster one
+    ceil3 = max(u["mfma_and_fragment_reads_only"]["tflops_algorithmic_3term"], u["whole_layer_loop"]["tflops_algorithmic_3term"])
     mix = ceil3 * 3.0 / issued
     roof["peak_sustained"] = {"value": mix, "unit": "TFLOP/s algorithmic", "three_term_layer": ceil3, "micro_kernel": u,
                               "note": "ceiling for THIS kernel's mix = 3-term ceiling x 3 / issued_over_algorithmic (the fp6-corrected colour "

@@ -1943,6 +1943,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 if (grp_done) break;
             }
         }
+#ifndef SDN_NO_TERM_GND   // (A/B switch for timing the main loop without this cold block; never set for a product build)
         if constexpr (FUSED) {
             // early termination dropped the group's remaining passes: their samples still take part in `is_gnd` (any sample of
             // the ray at world x <= 1, scenedreamer.py:380-382), as they do in encode_kernel -- place them (no gathers, no MLP)
@@ -1955,6 +1956,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     gnd = gnd || enc_place(enc, rb, dd, rl, c2 * SAMP_PER_STEP + (j & 3), ray_ok).gnd;
             }
         }
+#endif
         if (p.passes && threadIdx.x == 0) p.passes[grp] = (uint8_t)n_done;   // passes this group went through (tests / bench)
 
         // ---- blend the sky, store ---------------------------------------------------------------------------------

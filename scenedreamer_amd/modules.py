@@ -41,6 +41,7 @@ class Backend:
     in-place updates (load_state_dict, an optimizer step) and re-allocations (.cuda()) through the tensors' version counters
     and addresses, so packed weights are rebuilt exactly when they are stale."""
     mfma_cnn = Renderer.mfma_cnn
+    _cnn_form = Renderer._cnn_form
     set_precision = Renderer.set_precision
 
     def __init__(self):
