@@ -362,6 +362,48 @@ def other_configs(args, R, weights, scene, poses, dev):
     return recs
 
 
+def early_termination_record(args, R, weights, scene, poses, hw, mode):
+    """The north star's "wavefront ballots for early termination" measured: frames/s of the trajectory loop with the default
+    term_eps and with 0, on the benchmark weights (random-init: densities are low, few rays become opaque) and on an
+    opaque-surface variant of them (density-head bias + 4000: every hit ray is opaque after its first samples -- what a
+    trained checkpoint's terrain looks like to the ray), outside the timed region."""
+    from scenedreamer_amd import fused
+    from scenedreamer_amd.renderer import Renderer
+    default = float(fused.TERM_EPS_DEFAULT)
+    sel = [poses[(2 * k) % len(poses)] for k in range(8)]
+
+    def ms_per_frame(Rx, eps):
+        saved = getattr(Rx, "term_eps", None)
+        Rx.term_eps = eps
+        try:
+            for _ in Rx.render_frames(sel[:2], hw, args.samples, mode=mode, apron=args.apron):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in Rx.render_frames(sel, hw, args.samples, mode=mode, apron=args.apron):
+                pass
+            torch.cuda.synchronize()
+            ms = 1000.0 * (time.perf_counter() - t0) / len(sel)
+            _, _, ev = Rx.field_work(sel[:3], hw, args.samples, args.apron)
+        finally:
+            Rx.term_eps = saved
+        return ms, ev
+    rec = {"default_eps": default, "bound_on_net_out_change": 2 * default, "frames": len(sel)}
+    opaque = dict(weights)
+    opaque["render_net.fc_sigma.bias"] = np.asarray(weights["render_net.fc_sigma.bias"]) + 4000.0
+    Ro = Renderer(opaque, scene, R.dev)
+    Ro.set_style_code(R.z)
+    Ro.field_gate, Ro.cnn_calibration = {"path": "fused", "max_abs_err_vs_fp32": 0.0}, dict(R.cnn_calibration or {"terms3x3": 1, "pixels": 1 << 30,
+                                                                                                   "max_abs_diff_1term_vs_3term": 0.0, "bound": 0.0})
+    for name, Rx in (("benchmark_weights", R), ("opaque_surface_weights", Ro)):
+        on, ev_on = ms_per_frame(Rx, default)
+        off, _ = ms_per_frame(Rx, 0.0)
+        rec[name] = {"ms_per_frame_term_on": on, "ms_per_frame_term_off": off, "speedup": off / on,
+                     "passes_skipped_frac": ev_on["passes_skipped_by_termination"] / max(1.0, ev_on["passes_of_visited_groups"])}
+    del Ro
+    return rec
+
+
 def rvip_roofline(R, poses, hw):
     """SURVEY 8(d) record of the ray marcher: algorithmic bytes = 4 B x DDA steps of the reference's cell-by-cell loop
     (ray_voxel_intersection.cu:115-229; counted by the measurement build of the same kernel, sdn_rvip_debug_counts, WITHOUT the
@@ -573,6 +615,11 @@ def main():
         sdist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    tp_stats = None
+    if tile_parallel:       # one more frame, outside the timed region, with per-rank device timing of the bands
+        tp_stats = {}
+        sdist.render_frame_tile_parallel(R, frame_pose(args.warmup), hw, args.samples, mode=mode, stats=tp_stats)
+        barrier()
     frame_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     pct = lambda q: frame_ms[min(len(frame_ms) - 1, int(round(q * (len(frame_ms) - 1))))]
 
@@ -613,7 +660,7 @@ def main():
     roof_cnn = None
     if tile_parallel:     # per-kernel records on this rank's band (every rank does 1/N of the frame)
         roof, roof_grid = None, None
-    elif probe.get("mlp_kernel") and fused_eps(R) == 0.0:
+    elif probe.get("mlp_kernel"):
         # the launches of the timed region itself: average duration from HIP events recorded around every launch on the
         # stream it went to (main stream: mlp_kernel; side stream: encode_kernel), work averaged over the same poses
         ms_of = lambda k: float(np.mean([a.elapsed_time(b) for a, b in probe[k]]))
@@ -668,6 +715,9 @@ def main():
         roof_rvip = rvip_roofline(R, timed_poses, hw)
         if roof is not None and roof.get("bound") == "mfma" and not args.profile:
             sustained_ceiling(roof)
+    early = None
+    if rank == 0 and world == 1 and mode == "fused" and not tile_parallel and not args.no_extras:
+        early = early_termination_record(args, R, weights, scene, poses, hw, mode)
 
     if rank == 0:
         fps = (1 if tile_parallel else world) * args.steps / elapsed
@@ -683,7 +733,11 @@ def main():
                                    + ("1 frame per step, row bands over the ranks (tile-parallel)" if tile_parallel
                                       else "1 frame per rank per step"),
                        "baseline_config": args.config or (2 if (hw, args.samples, args.scene_size) == ((540, 960), 24, 2048) else None),
-                       "path": mode, "apron": "reference" if tile_parallel else args.apron,
+                       "path": mode, "apron": ("minimal" if mode == "fused" else "reference") if tile_parallel else args.apron,
+                       "bands": ({"rows": tp_stats.get("bands"), "band_ms": tp_stats.get("band_ms"), "imbalance_max_over_mean": tp_stats.get("imbalance"),
+                                  "cut": "equal estimated work (dist.balanced_row_bands on a 1/16-resolution ray cast)" if world > 1 else "one band",
+                                  "timing": "device events around each rank's own band work in one extra frame after the timed region"}
+                                 if tp_stats else None),
                        "field": ("one kernel (field_kernel: sample placement + hash-grid lookup + MLP + compositing)"
                                  if mode == "fused" and _single_kernel(R) else "encode_kernel -> HBM -> mlp_kernel") if mode == "fused" else None,
                        "ray_casting_overlap": not (args.no_overlap or mode != "fused"),
@@ -699,6 +753,7 @@ def main():
             "frame_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "delivered_frames_per_s_uint8_host": delivered_fps,
             "stage_ms": stage_ms, "setup_s": setup_s, "broadcast": bstats or None, f"ms_per_step_apron_{other}": other_ms,
             "roofline": roof, "roofline_grid_sampler": roof_grid, "roofline_cnn": roof_cnn, "roofline_rvip": roof_rvip,
+            "early_termination": early,
         }
         gates = {"cnn": getattr(R, "cnn_calibration", None),
                  "field": {k: v for k, v in (getattr(R, "field_gate", None) or {}).items() if k != "measurements"} or None,

@@ -89,18 +89,29 @@ def broadcast_large(t, src=0, min_numel=1 << 20):
         if rank != src:
             t.copy_(h)
         return t
-    if n < min_numel or n % world != 0 or not t.is_contiguous() or not _scatter_supported(t):
+    if n < min_numel or not t.is_contiguous() or not _scatter_supported(t):
         dist.broadcast(t, src)
         return t
-    chunk = n // world
+    # scatter + all_gather in `world` equal chunks; a tensor whose size is not a multiple of `world` is sent in chunks of
+    # ceil(n / world) elements with the last one zero-padded (it used to fall back to the flat, root-egress-bound broadcast)
+    chunk = -(-n // world)
     mine = torch.empty(chunk, dtype=t.dtype, device=t.device)
-    parts = [flat[i * chunk:(i + 1) * chunk].contiguous() for i in range(world)] if rank == src else None
+    parts = None
+    if rank == src:
+        parts = [flat[i * chunk:(i + 1) * chunk] for i in range(world)]
+        if parts[-1].numel() < chunk:
+            last = torch.zeros(chunk, dtype=t.dtype, device=t.device)
+            last[:parts[-1].numel()] = parts[-1]
+            parts[-1] = last
+        parts = [p.contiguous() for p in parts]
     dist.scatter(mine, parts, src=src)
     outs = [torch.empty(chunk, dtype=t.dtype, device=t.device) for _ in range(world)]
     dist.all_gather(outs, mine)
     if rank != src:
         for i, o in enumerate(outs):
-            flat[i * chunk:(i + 1) * chunk].copy_(o)
+            m = min(chunk, n - i * chunk)
+            if m > 0:
+                flat[i * chunk:i * chunk + m].copy_(o[:m])
     return t
 
 
@@ -195,29 +206,82 @@ def broadcast_state(scene, weights, style, dev, src=0, compact=True, stats=None)
 # Tile-parallel rendering of ONE frame (BASELINE.json config 5: 3840x2160 over 8 GPUs)
 # --------------------------------------------------------------------------------------------------------------
 def row_bands(height, world):
-    """Contiguous output-row bands, one per rank: [(row0, row1)] * world."""
+    """Contiguous output-row bands of equal HEIGHT, one per rank: [(row0, row1)] * world."""
     return [(height * k // world, height * (k + 1) // world) for k in range(world)]
 
 
-def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode="fused", group=None):
-    """Every rank renders one row band of the frame (with the CNN's 15-px apron, the same overlap the reference's tiles
-    use); the only exchange step of the path is the frame-wide sky mean: all_reduce(sum) of 64+1 numbers.  Rank 0
-    receives the stitched image [1,3,H,W]; the other ranks return None.
+MIN_BAND_ROWS = 8
+
+
+def balanced_row_bands(costs, world, min_rows=MIN_BAND_ROWS):
+    """Contiguous output-row bands of equal COST: costs[r] >= 0 is the relative work of output row r (Renderer.row_costs: the
+    field kernel only visits rays that hit something, so sky rows are nearly free and equal-height bands leave the ground bands
+    bounding the frame).  Boundary k is the first row where the running cost reaches k / world of the total; every band keeps at
+    least min_rows rows.  Deterministic in `costs`: ranks that computed the same costs cut the same bands."""
+    costs = np.asarray(costs, dtype=np.float64)
+    H = costs.shape[0]
+    if world <= 1 or H < world * min_rows or not np.isfinite(costs).all() or costs.sum() <= 0:
+        return row_bands(H, world)
+    cum = np.cumsum(np.maximum(costs, 0.0))
+    cuts = [0]
+    for k in range(1, world):
+        r = int(np.searchsorted(cum, cum[-1] * k / world, side="left")) + 1
+        r = max(r, cuts[-1] + min_rows)
+        r = min(r, H - (world - k) * min_rows)
+        cuts.append(r)
+    cuts.append(H)
+    return [(cuts[k], cuts[k + 1]) for k in range(world)]
+
+
+def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode="fused", group=None, balance=True, stats=None):
+    """Every rank renders one row band of the frame; the only exchange step of the path is the frame-wide sky mean:
+    all_reduce(sum) of 64+1 numbers.  Rank 0 receives the stitched image [1,3,H,W]; the other ranks return None.
+
+    balance: bands of equal estimated work (balanced_row_bands on renderer.row_costs(pose, hw): a 1/16-resolution ray cast every
+    rank performs for itself -- bit-identical everywhere, so no exchange) instead of equal height.
+    stats: optional dict; receives "bands", and -- measured with device events around this rank's work, exchanged in one extra
+    all_reduce of `world` numbers -- "band_ms" (per rank) and "imbalance" = max / mean.
 
     `renderer` needs band_prepare(pose, hw, row0, row1, mode) -> {"sky_sum" f64[64], "sky_cnt" int, ...} and
-    band_finish(handle, sky_avg[1,64], num_samples) -> image rows; scenedreamer_amd.renderer.Renderer provides both."""
+    band_finish(handle, sky_avg[1,64], num_samples) -> image rows; scenedreamer_amd.renderer.Renderer provides both (and
+    row_costs)."""
     world = dist.get_world_size(group) if _is_init() else 1
     rank = dist.get_rank(group) if _is_init() else 0
     H, W = resolution_hw
-    bands = row_bands(H, world)
+    if balance and world > 1 and hasattr(renderer, "row_costs"):
+        bands = balanced_row_bands(renderer.row_costs(pose, resolution_hw), world)
+    else:
+        bands = row_bands(H, world)
     row0, row1 = bands[rank]
+    timed = stats is not None and torch.cuda.is_available() and getattr(renderer, "dev", torch.device("cpu")).type == "cuda"
+    if timed:
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
     hd = renderer.band_prepare(pose, resolution_hw, row0, row1, mode)
     red = torch.cat([hd["sky_sum"].to(torch.float64).reshape(64),
                      torch.tensor([float(hd["sky_cnt"])], dtype=torch.float64, device=hd["sky_sum"].device)])
+    if timed:
+        e1.record()
     if world > 1:
         all_reduce(red, op=dist.ReduceOp.SUM, group=group)
     sky_avg = (red[:64] / red[64]).to(torch.float32).reshape(1, 64)
+    if timed:
+        e2.record()
     img = renderer.band_finish(hd, sky_avg, num_samples)
+    if stats is not None:
+        stats["bands"] = bands
+        if timed:
+            e3 = torch.cuda.Event(enable_timing=True)
+            e3.record()
+            e3.synchronize()
+            mine = e0.elapsed_time(e1) + e2.elapsed_time(e3)       # this rank's own work: prepare + finish (the wait in the all_reduce excluded)
+            v = torch.zeros(world, dtype=torch.float64, device=img.device)
+            v[rank] = mine
+            if world > 1:
+                all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+            ms = [float(x) for x in v.tolist()]
+            stats["band_ms"] = ms
+            stats["imbalance"] = max(ms) / (sum(ms) / len(ms)) if sum(ms) > 0 else None
     if world == 1:
         return img
     hmax = max(b[1] - b[0] for b in bands)

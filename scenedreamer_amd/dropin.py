@@ -235,8 +235,6 @@ def fast_forward_perpix(self, blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z
         if not self.coarse_deterministic_sampling:            # the reference's draw, mc_utils.py:121 (nsamples = num_samples + 1)
             u = torch.rand([1, h, w, ns + 1, 1], dtype=depth2.dtype, device=depth2.device).reshape(h * w, ns + 1)
         aux = {} if b.aux else None
-        if aux is not None and fused.precision_profile(B)[1] > 0:
-            raise RuntimeError("aux outputs need early ray termination off (term_eps = 0)")
         net_out = fused.field_render(B, vid, d2, rd, cam_ori_t, sky_c, sky_avg, ns, u=u, window=win, aux=aux)
         out = [None] * len(PERPIX_OUTPUTS)
         out[0] = net_out.view(1, h, w, 64)

@@ -436,7 +436,8 @@ class Renderer:
                   else "auto (1-term if within 5e-4 of the 3-term image, not yet calibrated)")
         else:
             t3 = f"{t3}-term (set explicitly)"
-        return (f"f32 (hash grid) + f16 MFMA with f32 accumulate: field/sky MLP 3-term split"
+        eps = fused.precision_profile(self)[1]
+        return (f"f32 (hash grid) + f16 MFMA with f32 accumulate{f' (early ray termination at transmittance {eps:g})' if eps > 0 else ''}: field/sky MLP 3-term split"
                 f"{' (colour layers 2-term)' if ct == 2 else ' (colour layers: f16 Whi.Xhi + MX-fp6 corrections)' if ct == 6 else ''}"
                 f", render CNN 1x1 3-term / 3x3 {t3}")
 
@@ -485,26 +486,41 @@ class Renderer:
                                      "outside the timed region")
 
     def field_work(self, poses, resolution_hw, num_samples, apron="minimal"):
-        """What the field kernels of the fused frame loop process for these poses, averaged per frame (outside any timed
-        region: one ray cast per pose): samples per launch, fraction of rays that hit something, and the samples
-        mlp_kernel evaluates (it visits only 32-ray groups with a hit; early termination must be off)."""
+        """What the field kernel of the fused frame loop processes for these poses, averaged per frame (outside any timed
+        region): samples per launch, fraction of rays that hit something, and the samples the kernel EVALUATES -- it visits only
+        32-ray groups with a hit, and with early termination on (the default) it drops a group's remaining passes once all its
+        rays are opaque: the executed passes are then counted by launching the kernel once per pose with a `passes` buffer."""
         from . import fused
         crop = self.pad // 2
         o = crop - CNN_HALO if (apron == "minimal" and crop > CNN_HALO) else 0
         nch = -(-num_samples // 4)
-        B = hits = groups = evald = 0.0
+        eps = fused.precision_profile(self)[1]
+        B = hits = groups = evald = skipped = 0.0
         with torch.no_grad():
             for pose in poses:
-                vid, _, _, (H0, W0) = self.cast_rays(pose, resolution_hw)
+                vid, d2, rd, (H0, W0) = self.cast_rays(pose, resolution_hw)
                 hit = (vid.view(H0, W0, self.M)[o:H0 - o, o:W0 - o, 0] != 0).reshape(-1)
                 n = hit.numel()
                 g = torch.nn.functional.pad(hit, (0, (-n) % 32)).view(-1, 32).any(dim=1)
                 B += n * num_samples
                 hits += float(hit.float().mean())
                 groups += float(g.float().mean())
-                evald += int(g.sum()) * 32 * nch * 4
+                if eps > 0 and fused.single_kernel(self):
+                    n0 = H0 * W0
+                    v, d, r = vid.view(n0, self.M), d2.view(2, n0, self.M), rd.view(n0, 3)
+                    sky_c, sky_avg = fused.sky_fused(self, r)
+                    win = fused.Window.crop(H0, W0, o)
+                    pa = torch.zeros((win.n_rays + 31) // 32, dtype=torch.uint8, device=self.dev)
+                    fused.field_render(self, v, d, r, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, num_samples,
+                                       passes=pa, window=win)
+                    executed = int(pa.sum(dtype=torch.int64))
+                    evald += executed * 128
+                    skipped += int((pa > 0).sum()) * nch - executed
+                else:
+                    evald += int(g.sum()) * 32 * nch * 4
         k = max(1, len(poses))
-        return B / k, hits / k, dict(group_hit_fraction=groups / k, evaluated_samples=evald / k, passes_skipped_by_termination=0)
+        return B / k, hits / k, dict(group_hit_fraction=groups / k, evaluated_samples=evald / k, passes_skipped_by_termination=skipped / k,
+                                     passes_of_visited_groups=(evald / 128 + skipped) / k)
 
     def roofline_records(self, B, ms_enc, ms_mlp, hit, ev, kernel, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0, timing="",
                          field_kernel=False):
@@ -566,19 +582,48 @@ class Renderer:
         return mlp, grid
 
     # ------------------------------------------------------------------ row bands (tile-parallel single frame)
-    def band_prepare(self, pose, resolution_hw, row0, row1, mode="fused"):
-        """Cast the rays needed for output rows [row0,row1) (padded rows [row0, row1+pad)) and evaluate the sky MLP.
-        Returns a handle with the band's share of the frame-wide sky sum: padded rows [row0,row1) are owned by this
-        band, the band that ends the frame also owns the trailing `pad` rows, so every ray is counted exactly once
-        (sky_avg is the mean over ALL rays of the padded frame, scenedreamer.py:592-598)."""
+    def row_costs(self, pose, resolution_hw, scale=4):
+        """Relative cost of every OUTPUT row of the frame, for cutting it into bands of equal work (dist.balanced_row_bands):
+        the field kernel visits only rays that hit something (sky rows cost almost nothing there), every ray costs ray casting,
+        sky MLP and CNN.  Estimated from a 1/scale-resolution ray cast of the padded frame (1/16 of the rays; deterministic and
+        bit-identical on every rank, so all ranks cut the same bands without talking): cost(row) = hits(row) + MISS_COST * width."""
         cam_ori, cam_dir, cam_up, cam_f = pose
         H, W = resolution_hw
         f, c, cam_res = frame_intrinsics(cam_f, resolution_hw, self.pad)
-        p0, p1 = row0, row1 + self.pad
+        Hq, Wq = -(-cam_res[0] // scale), -(-cam_res[1] // scale)
+        off = (scale - 1) / 2.0
+        with torch.no_grad():
+            vid, _, _ = ops.ray_voxel_intersection_perspective(self.volume, cam_ori, cam_dir, cam_up, f / scale,
+                                                               [(c[0] - off) / scale, (c[1] - off) / scale], [Hq, Wq], 1, palette=self.palette)
+            hits_q = (vid.view(Hq, Wq) != 0).sum(dim=1).cpu().numpy().astype(np.float64) * scale      # hits per padded row, estimated
+        pad_rows = np.minimum(np.arange(H) + self.pad // 2, cam_res[0] - 1)       # the padded row at the centre of output row r's apron
+        return hits_q[pad_rows // scale] + MISS_COST * cam_res[1]
+
+    def band_prepare(self, pose, resolution_hw, row0, row1, mode="fused", apron="minimal"):
+        """Cast the rays needed for output rows [row0,row1) and evaluate the sky MLP on them.  Returns a handle with the band's
+        share of the frame-wide sky sum (sky_avg is the mean over ALL rays of the padded frame, scenedreamer.py:592-598: every
+        padded row is owned by exactly one band).
+        apron: the reference's tiles carry 15 px of apron per side (pad / 2); only CNN_HALO = 4 px can reach a kept pixel.
+        "minimal" (fused mode): the band casts padded rows [row0 + 11, row1 + 19) -- the first / last band additionally the
+        frame's top / bottom rows, which only the sky mean needs -- and evaluates the field and the CNN on its 4-px apron;
+        "reference": padded rows [row0, row1 + 30), everything evaluated (the un-fused path always does)."""
+        cam_ori, cam_dir, cam_up, cam_f = pose
+        H, W = resolution_hw
+        f, c, cam_res = frame_intrinsics(cam_f, resolution_hw, self.pad)
+        Wp = cam_res[1]
+        crop = self.pad // 2
+        o = crop - CNN_HALO if (mode == "fused" and apron == "minimal" and crop > CNN_HALO) else 0
+        # padded rows this band casts / owns for the sky sum / evaluates the field on
+        p0 = 0 if row0 == 0 else row0 + o
+        p1 = cam_res[0] if row1 == H else row1 + self.pad - o
+        own0 = 0 if row0 == 0 else row0 + crop
+        own1 = cam_res[0] if row1 == H else row1 + crop
+        if o == 0:                       # reference apron: the ownership of rounds 2-3 (rows [row0, row1) + the trailing pad)
+            p0, own0, own1 = row0, row0, (cam_res[0] if row1 == H else row1)
+        e0, e1 = row0 + o, row1 + self.pad - o
         # same rays as the full frame: ndc_y = c0 - row_global = (c0 - p0) - row_local, exact in float32
         vid, d2, rd = ops.ray_voxel_intersection_perspective(self.volume, cam_ori, cam_dir, cam_up, f, [c[0] - p0, c[1]],
-                                                             [p1 - p0, cam_res[1]], self.M, palette=self.palette)
-        Wp = cam_res[1]
+                                                             [p1 - p0, Wp], self.M, palette=self.palette)
         n = (p1 - p0) * Wp
         vid, d2, rd = vid.view(n, self.M), d2.view(2, n, self.M), rd.view(n, 3)
         with torch.no_grad():
@@ -587,9 +632,9 @@ class Renderer:
                 sky_c, _ = fused.sky_fused(self, rd)
             else:
                 sky_c = self.sky_features(rd)
-            own1 = (row1 - row0 + (self.pad if row1 == H else 0)) * Wp
-            sky_sum = sky_c[:own1].sum(dim=0, dtype=torch.float64)
-        return dict(vid=vid, d2=d2, rd=rd, sky_c=sky_c, sky_sum=sky_sum, sky_cnt=own1, rows=(p1 - p0), Wp=Wp,
+            sky_sum = sky_c[(own0 - p0) * Wp:(own1 - p0) * Wp].sum(dim=0, dtype=torch.float64)
+        return dict(vid=vid, d2=d2, rd=rd, sky_c=sky_c, sky_sum=sky_sum, sky_cnt=(own1 - own0) * Wp, cast_rows=(p1 - p0), Wp=Wp,
+                    rows=(e1 - e0), cols=Wp - 2 * o, first=(e0 - p0) * Wp + o, halo=crop - o,
                     cam_ori=(torch.as_tensor(cam_ori, dtype=torch.float32) if mode == "fused"
                              else torch.as_tensor(cam_ori, dtype=torch.float32).to(self.dev)), mode=mode)
 
@@ -598,23 +643,32 @@ class Renderer:
         mode = hd["mode"]
         with torch.no_grad():
             sky_avg = sky_avg.to(torch.float32).reshape(1, 64)
+            full = hd["rows"] == hd["cast_rows"] and hd["cols"] == hd["Wp"]
             if mode == "fused" and self.field_falls_back():      # (the job-wide decision of dist.agree_precision)
                 mode, hd["cam_ori"] = "unfused", hd["cam_ori"].to(self.dev)
             if mode == "fused":
                 from . import fused
+                win = None if full else fused.Window(hd["cast_rows"] * hd["Wp"], hd["Wp"], hd["first"], hd["rows"], hd["cols"])
                 net_out = fused.field_fused(self, hd["vid"], hd["d2"], hd["rd"], hd["cam_ori"], hd["sky_c"], sky_avg,
-                                            num_samples)
+                                            num_samples, window=win)
             else:
-                net_out = self.field_unfused(hd["vid"], hd["d2"], hd["rd"], hd["cam_ori"], hd["sky_c"], sky_avg, num_samples)
-            net_out = net_out.view(1, hd["rows"], hd["Wp"], 64)
+                vid, d2, rd, sky_c = hd["vid"], hd["d2"], hd["rd"], hd["sky_c"]
+                if not full:             # (a fused band that fell back: cut the evaluated window out of the cast block)
+                    y0, x0 = divmod(hd["first"], hd["Wp"])
+                    cut = lambda t: t.view(hd["cast_rows"], hd["Wp"], -1)[y0:y0 + hd["rows"], x0:x0 + hd["cols"]].reshape(hd["rows"] * hd["cols"], -1)
+                    vid, rd, sky_c = cut(vid), cut(rd), cut(sky_c)
+                    d2 = torch.stack([cut(d2[0]), cut(d2[1])])
+                net_out = self.field_unfused(vid.contiguous(), d2.contiguous(), rd.contiguous(), hd["cam_ori"], sky_c.contiguous(), sky_avg,
+                                             num_samples)
+            net_out = net_out.view(1, hd["rows"], hd["cols"], 64)
             if cnn_mode is None:
                 cnn_mode = "mfma" if mode == "fused" else "torch"
             if cnn_mode == "mfma":
                 img = self.mfma_cnn(net_out)(net_out)
             else:
                 img = self.render_cnn(net_out)
-            p = self.pad // 2
-            return img[:, :, p:-p, p:-p] if self.pad else img
+            p = hd["halo"]
+            return img[:, :, p:-p, p:-p] if p else img
 
     # ------------------------------------------------------------------ frame
     def render_frame(self, pose, resolution_hw=(540, 960), num_samples=24, mode="unfused", cnn=True,
@@ -820,6 +874,7 @@ FIELD_AUTO_BOUND = 8e-4    # largest net_out error of the fused field vs the fp3
 IMAGE_AUTO_BOUND = 8e-4    # largest image error of the whole fused path vs the fp32 path, whole frame
 CAL_MAX_PIXELS = 1 << 20   # frames above this many pixels are calibrated at a reduced resolution (same pose)
 CAL_CHUNK = 1 << 16        # rays per launch group of the fp32 field
+MISS_COST = 0.2            # row_costs: cost of a ray that hits nothing relative to one that does (ray casting + sky MLP + CNN vs + field)
 FIELD_GATE = os.environ.get("SDN_FIELD_GATE", "1") != "0"   # (0: no field calibration -- kernel timing experiments only)
 CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (conv2a, conv2b, conv3a, conv3b)
 

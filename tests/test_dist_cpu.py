@@ -39,6 +39,11 @@ def _worker(rank, world, port, q):
         t = torch.arange(1 << 21, dtype=torch.int32) if rank == 0 else torch.empty(1 << 21, dtype=torch.int32)
         sdist.broadcast_large(t, 0)
         ok = ok and bool((t == torch.arange(1 << 21, dtype=torch.int32)).all())
+        # ... whose size is NOT a multiple of the world size: padded last chunk, still scatter + all_gather
+        n_odd = (1 << 20) + 3
+        t = torch.arange(n_odd, dtype=torch.float32).reshape(-1) if rank == 0 else torch.full((n_odd,), -1.0)
+        sdist.broadcast_large(t, 0)
+        ok = ok and bool((t == torch.arange(n_odd, dtype=torch.float32)).all())
         frames = sdist.shard_frames(range(11), rank, world)
         q.put((rank, ok, frames))
     finally:
@@ -123,3 +128,23 @@ def test_tile_parallel_single_frame_world2():
     assert res[1] is None and res[0].shape == (1, 3, H, W)
     np.testing.assert_allclose(res[0], single, rtol=0, atol=1e-6)
     assert sdist.row_bands(37, 2) == [(0, 18), (18, 37)] and sdist.row_bands(2160, 8)[-1] == (1890, 2160)
+
+
+def test_balanced_row_bands():
+    """Bands of equal estimated work: a frame whose upper third is sky (cheap rows) gets a tall first band; degenerate cost
+    vectors fall back to equal heights; every band keeps MIN_BAND_ROWS rows; the cuts are a pure function of the costs."""
+    from scenedreamer_amd import dist as sdist
+    W = 990
+    costs = np.r_[np.full(200, 0.2 * W), np.full(340, 0.2 * W + 0.9 * W)]
+    bands = sdist.balanced_row_bands(costs, 8)
+    assert bands[0][0] == 0 and bands[-1][1] == 540 and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+    work = [costs[a:b].sum() for a, b in bands]
+    assert max(work) / (sum(work) / 8) < 1.03 and bands[0][1] - bands[0][0] > 150
+    equal = [costs[a:b].sum() for a, b in sdist.row_bands(540, 8)]
+    assert max(equal) / (sum(equal) / 8) > 1.3                       # what equal-height bands would cost
+    assert sdist.balanced_row_bands(costs, 8) == bands
+    assert sdist.balanced_row_bands(np.zeros(100), 4) == sdist.row_bands(100, 4)
+    assert sdist.balanced_row_bands(np.ones(20), 4) == sdist.row_bands(20, 4)           # too few rows for 4 bands of 8
+    tail = sdist.balanced_row_bands(np.r_[np.zeros(90), np.ones(10)], 4)
+    assert all(b - a >= sdist.MIN_BAND_ROWS for a, b in tail) and tail[-1][1] == 100
+    assert sdist.balanced_row_bands(np.ones(540), 1) == [(0, 540)]

@@ -95,6 +95,93 @@ def test_two_ranks_on_one_gpu_equal_single_process():
     assert d < (5e-4 if cal["terms3x3"] == 1 else 1e-6)
 
 
+def _worker8(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from scenedreamer_amd import camera
+        from scenedreamer_amd import dist as sdist
+        from scenedreamer_amd.renderer import Renderer
+        dev = torch.device("cuda", 0)
+        scene, weights, style = _state() if rank == 0 else (None, None, None)
+        sc, w, st = sdist.broadcast_state(scene, weights, style, dev, src=0, compact=True)
+        R = Renderer(w, sc, dev)
+        R.set_style(st)
+        poses = camera.eval_camera_poses(sc, maxstep=8)
+        gates = sdist.agree_precision(R, poses[0], HW, NS)
+        mine = sdist.shard_frames(range(8), rank, world)
+        imgs = {f: im.clone().cpu().numpy() for f, im in zip(mine, R.render_frames([poses[f] for f in mine], HW, NS, mode="fused"))}
+        stats = {}
+        tp = sdist.render_frame_tile_parallel(R, poses[TP_POSE], HW, NS, mode="fused", stats=stats)
+        q.put((rank, imgs, None if tp is None else tp.cpu().numpy(), stats, {k: (v or {}).get("agreed_over_ranks") for k, v in gates.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_on_one_gpu_equal_single_process():
+    """The shapes the 8-GPU node will run -- 8 ranks: state broadcast (a table whose size is not a multiple of 8 included),
+    job-wide precision gates, frames f -> rank f % 8, and ONE frame as 8 work-balanced row bands with the minimal apron --
+    with 8 processes sharing this box's GPU over gloo.  Sharded frames equal a single process bit for bit; the banded frame
+    equals the full frame to the CNN's error level; the bands tile the frame and follow the per-row work estimate."""
+    from scenedreamer_amd import camera
+    from scenedreamer_amd import dist as sdist
+    from scenedreamer_amd import scene as scene_mod
+    from scenedreamer_amd.renderer import Renderer
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    scene, weights, style = _state()
+    R = Renderer(weights, scene_mod.to_compact(scene), "cuda")
+    R.set_style(style)
+    poses = camera.eval_camera_poses(scene, maxstep=8)
+    sdist.agree_precision(R, poses[0], HW, NS)
+    single = [R.render_frame(poses[f], HW, NS, mode="fused").cpu().numpy() for f in range(8)]
+    tp_single = R.render_frame(poses[TP_POSE], HW, NS, mode="fused").cpu().numpy()
+    costs = R.row_costs(poses[TP_POSE], HW)
+    res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for r, imgs, tp, stats, agreed in res:
+        assert sorted(imgs) == [r] and agreed == {"cnn": 8, "field": 8}
+        np.testing.assert_array_equal(imgs[r], single[r])
+        assert (tp is None) == (r != 0)
+        assert stats["bands"] == res[0][3]["bands"] and len(stats["band_ms"]) == 8 and min(stats["band_ms"]) > 0
+    bands = res[0][3]["bands"]
+    assert bands == sdist.balanced_row_bands(costs, 8) and bands[0][0] == 0 and bands[-1][1] == HW[0]
+    assert all(a[1] == b[0] for a, b in zip(bands, bands[1:])) and all(b - a >= sdist.MIN_BAND_ROWS for a, b in bands)
+    d = float(np.abs(res[0][2] - tp_single).max())
+    print(f"tile-parallel over 8 ranks (bands {bands}, band_ms {[round(x, 2) for x in res[0][3]['band_ms']]}) vs single process: max abs diff {d:.2e}")
+    assert d < 5e-4
+
+
+def test_bench_py_self_launches_for_gpus_n():
+    """`python bench.py --gpus 2 ...` as a PLAIN command (no launcher, no WORLD_SIZE): it re-executes itself under
+    torch.distributed.run and reports n_gpus 2; a WORLD_SIZE that contradicts --gpus is an error, not a smaller job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    bench = [sys.executable, os.path.join(root, "bench.py")]
+    small = ["--steps", "2", "--warmup", "1", "--scene-size", "256", "--height", "96", "--width", "136", "--samples", "12", "--no-extras"]
+    r = subprocess.run(bench + ["--gpus", "2", "--backend", "gloo"] + small, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+    bad = subprocess.run(bench + ["--gpus", "4", "--backend", "gloo"] + small, capture_output=True, text=True, timeout=120, cwd=root,
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "--gpus 4 but WORLD_SIZE=1" in bad.stderr
+    if torch.cuda.device_count() == 1:          # RCCL: one GPU per rank, or an error -- never a silently smaller job
+        nccl = subprocess.run(bench + ["--gpus", "2", "--backend", "nccl"] + small, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+        assert nccl.returncode != 0 and "only 1 GPU(s) visible" in nccl.stderr
+
+
 def _nccl_worker(port, q):
     """world_size 1 on the RCCL backend: no peer to talk to, but every collective dist.py issues is dispatched to RCCL with the
     dtypes it uses -- an op or dtype the backend does not implement raises here instead of on the first multi-GPU job."""
@@ -174,5 +261,8 @@ def test_bench_py_multi_rank_path_two_ranks_on_one_gpu(bench_mode):
     assert d["scaling"] == ("strong" if bench_mode == "tile-parallel" else "weak")
     assert d["config"]["dist_backend"].startswith("gloo, 2 ranks on 1 GPU")
     assert d["config"]["parallelism"] == ("row bands x2" if bench_mode == "tile-parallel" else "frames x2")
+    if bench_mode == "tile-parallel":
+        b = d["config"]["bands"]
+        assert len(b["rows"]) == 2 and b["rows"][0][0] == 0 and b["rows"][1][1] == 96 and len(b["band_ms"]) == 2 and b["imbalance_max_over_mean"] >= 1.0
     if bench_mode == "frames":
         assert d["broadcast"]["scene_volume_bytes"] > 0 and "cpu_baseline" not in d      # compact volume; no CPU leg at N > 1
