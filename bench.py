@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=24)
     ap.add_argument("--scene-size", type=int, default=2048)
     ap.add_argument("--apron", default="minimal", choices=["minimal", "reference"],
-                    help="field/CNN evaluated on the 4-px apron the image can depend on (bit-identical image), or on the "
+                    help="field/CNN evaluated on the 4-px apron the image can depend on (the same image), or on the "
                          "reference's full 15-px apron")
     ap.add_argument("--no-overlap", action="store_true", help="do not cast the next frame's rays on a second stream")
     ap.add_argument("--no-extras", action="store_true",
@@ -749,7 +749,8 @@ def main():
                        "dist_backend": (args.backend + (f", {world} ranks on {ndev} GPU(s)" if world > ndev else "")) if world > 1 else None,
                        "apron_note": "ray casting and the sky MLP always cover the reference's padded frame (15-px apron); "
                                      "'minimal' evaluates the field MLP and the CNN on the 4-px apron that can reach a kept "
-                                     "pixel -- the image is bit-identical (tests/test_render_gpu.py, test_fullsize_gpu.py)"},
+                                     "pixel -- the same image: bit-identical with term_eps = 0, within the early-termination bound (< 2e-4) otherwise "
+                                     "(tests/test_render_gpu.py, test_fullsize_gpu.py)"},
             "frame_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "delivered_frames_per_s_uint8_host": delivered_fps,
             "stage_ms": stage_ms, "setup_s": setup_s, "broadcast": bstats or None, f"ms_per_step_apron_{other}": other_ms,
             "roofline": roof, "roofline_grid_sampler": roof_grid, "roofline_cnn": roof_cnn, "roofline_rvip": roof_rvip,

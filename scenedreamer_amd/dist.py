@@ -248,6 +248,11 @@ def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode=
     world = dist.get_world_size(group) if _is_init() else 1
     rank = dist.get_rank(group) if _is_init() else 0
     H, W = resolution_hw
+    if (world > 1 and mode == "fused" and hasattr(renderer, "calibrate_style") and getattr(renderer, "field_gate", None) is None and
+            getattr(renderer, "cnn_terms3x3", None) is None):
+        # bands of one frame must not mix precisions: the per-style gates are decided for the job before the first band (every
+        # rank reaches this point for the same frame with the same, still undecided, state -- the style was set on all of them)
+        agree_precision(renderer, pose, (min(H, 540), min(W, 960)), num_samples, group)
     if balance and world > 1 and hasattr(renderer, "row_costs"):
         bands = balanced_row_bands(renderer.row_costs(pose, resolution_hw), world)
     else:

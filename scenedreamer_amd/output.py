@@ -72,7 +72,8 @@ def open_video(path, fps=10, backend="auto"):
     if backend in ("auto", "imageio"):
         try:
             return _ImageioVideo(path, fps)
-        except (ImportError, AttributeError, NotImplementedError):   # absent, or an inert stand-in without a writer
+        except Exception:   # noqa: BLE001 -- imageio absent (ImportError), an inert stand-in (AttributeError / NotImplementedError),
+            # or present without a video plugin: imageio v3 raises ValueError ("Could not find a backend ...") for .mp4 then
             if backend == "imageio":
                 raise
     from .mp4 import Mp4MjpegWriter

@@ -5,13 +5,23 @@ import os
 import numpy as np
 import torch
 
+_ABSENT = object()
+
 
 def stub_writers():
-    """Returns the list that will receive every frame handed to the video writer."""
+    """Returns (the list that will receive every frame handed to the video writer, undo())."""
     import cv2
     import imageio
     from PIL import Image
     frames = []
+    before = [(m, k, m.__dict__.get(k, _ABSENT)) for m in (cv2, imageio) for k in ("imwrite", "IMWRITE_PNG_COMPRESSION", "get_writer")]
+
+    def undo():
+        for m, k, v in before:
+            if v is _ABSENT:
+                m.__dict__.pop(k, None)
+            else:
+                m.__dict__[k] = v
 
     def imwrite(path, img, params=None):
         img = np.asarray(img)
@@ -28,17 +38,20 @@ def stub_writers():
     cv2.__dict__["imwrite"] = imwrite
     cv2.__dict__["IMWRITE_PNG_COMPRESSION"] = 16
     imageio.__dict__["get_writer"] = lambda path, fps=10: _Rec()
-    return frames
+    return frames, undo
 
 
 def run_reference_loop(G, out_dir, hw, ns, steps, tile_size=64, style_seed=8888, camera_mode=0):
     """G.inference_givenstyle on the synthetic style; returns the RGB uint8 frames the loop produced (also written as PNGs)."""
     from scenedreamer_amd import synth
-    frames = stub_writers()
+    frames, undo = stub_writers()
     style = torch.from_numpy(np.asarray(synth.make_style(style_seed))).cuda()
-    with torch.no_grad():
-        G.inference_givenstyle(style, out_dir, camera_mode=camera_mode, num_samples=ns, tile_size=tile_size, resolution_hw=list(hw),
-                               cam_ang=72, cam_maxstep=steps)
+    try:
+        with torch.no_grad():
+            G.inference_givenstyle(style, out_dir, camera_mode=camera_mode, num_samples=ns, tile_size=tile_size, resolution_hw=list(hw),
+                                   cam_ang=72, cam_maxstep=steps)
+    finally:
+        undo()          # (the stand-in modules live in sys.modules for the rest of the test process)
     rdir = os.path.join(out_dir, "rgb_render")
     assert len(frames) == steps and all(os.path.exists(os.path.join(rdir, f"{i:05d}.png")) for i in range(steps))
     return frames

@@ -4,8 +4,8 @@ literal CPU restatement (oracle/field_ref.render_frame_tiled: C ray marcher pinn
 Python layers pinned by the goldens) and compared with the same pixels of the fused HIP frame.  Tolerance: 1e-3 abs on
 the image (north star).  Config 2 is checked on ONE WHOLE FRAME (all 40 tiles, ~1-2 min of CPU) plus sampled tiles of
 other poses, on the very path bench.py times (compact uint8 volume + pipelined render_frames + minimal apron); configs
-3 and 5 on sampled tiles (of 135 / 510), always including a frame corner, and for config 5 a tile that straddles a row-
-band seam of the tile-parallel renderer."""
+3 and 5 on sampled tiles (of 135 / 510), always including a frame corner, and for config 5 two tiles on every row-band seam
+of the tile-parallel renderer (32 tiles)."""
 import numpy as np
 import pytest
 import torch
@@ -110,30 +110,12 @@ def test_config2_bench_path_other_pose_tiles_against_oracle(big, bench_path, lut
                  render=_pipelined(bench_path, poses, 30, (540, 960), 24))
 
 
-def test_config5_tiles_against_oracle(big, lut):
-    """BASELINE config 5 (3840x2160, 40 samples/ray): the frame rendered as 8 row bands exactly as
-    dist.render_frame_tile_parallel does on 8 ranks (band_prepare on every band, the frame-wide sky mean stitched from
-    the bands' sums, band_finish), against oracle tiles: a frame corner with the ragged last row/column of the
-    reference's 17 x 30 tile grid, and a tile that straddles the seam between bands 0 and 1 (rows 256..383, seam at 270)."""
-    R, scene, poses, w, vox_np = big
-    hw, ns, world = (2160, 3840), 40, 8
-
-    def render(_R, pose):
-        from scenedreamer_amd.dist import row_bands
-        bands = row_bands(hw[0], world)
-        assert bands[0][1] == 270 and bands[-1][1] == hw[0]
-        hds = [R.band_prepare(pose, hw, r0, r1, mode="fused") for r0, r1 in bands]
-        tot, cnt = sum(h["sky_sum"] for h in hds), sum(h["sky_cnt"] for h in hds)
-        assert cnt == (hw[0] + R.pad) * (hw[1] + R.pad)
-        sky_avg = (tot / cnt).to(torch.float32)
-        return torch.cat([R.band_finish(h, sky_avg, ns) for h in hds], dim=2)
-
-    _check_tiles(big, lut, hw, ns, 17, lambda nh, nw: [(nh - 1, nw - 1), (2, nw // 2)], 510, render=render)
-
-
 def test_config5_every_band_seam_against_oracle(big, lut):
-    """32 of the 510 tiles of a config-5 frame rendered as 8 row bands: two tiles on EVERY one of the 7 band seams (rows 270,
-    540, ... 1890), the four frame corners, and 14 more spread over the frame (seeded) -- max abs error recorded for profiles/."""
+    """BASELINE config 5 (3840x2160, 40 samples/ray): the frame rendered as 8 row bands exactly as
+    dist.render_frame_tile_parallel does on 8 ranks (band_prepare on every band -- minimal apron --, the frame-wide sky mean
+    stitched from the bands' sums, band_finish), against 32 of the 510 oracle tiles: two tiles on EVERY one of the 7 band seams
+    (rows 270, 540, ... 1890), the four frame corners (with the ragged last row / column of the reference's 17 x 30 tile grid),
+    and 14 more spread over the frame (seeded) -- max abs error recorded for profiles/."""
     import json
     import os
     R, scene, poses, w, vox_np = big
@@ -190,8 +172,8 @@ def test_row_bands_equal_full_frame(big, terms3x3, bound):
     R, scene, poses, w, _ = big
     hw, ns = (540, 960), 24
     pose = poses[9]
-    R.set_precision(cnn_terms3x3=terms3x3)
-    try:
+    R.set_precision(cnn_terms3x3=terms3x3, term_eps=0.0)      # (every sample evaluated: with early termination the 32-ray groups of
+    try:                                                       #  a band differ from the full frame's, agreement is then ~1e-5)
         full = R.render_frame(pose, hw, ns, mode="fused")
         bounds = [0, 173, 361, 540]
         hds = [R.band_prepare(pose, hw, bounds[i], bounds[i + 1], mode="fused") for i in range(3)]

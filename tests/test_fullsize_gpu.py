@@ -159,7 +159,7 @@ def test_trajectory_to_png_and_mp4_keeps_pace(big, tmp_path):
         pass
     torch.cuda.synchronize()
     render_fps = len(sel) / (time.perf_counter() - t0)
-    w = FrameWriter(str(tmp_path / "png"), fmt="png", video_path=str(tmp_path / "out.mp4"), fps=10)
+    w = FrameWriter(str(tmp_path / "png"), fmt="png", video_path=str(tmp_path / "out.mp4"), fps=10, video_backend="mjpeg")   # (the test parses the MJPEG container)
     keep = {}
     t0 = time.perf_counter()
     for i, img in enumerate(R.render_frames(sel, (540, 960), 24, mode="fused")):

@@ -246,7 +246,7 @@ def test_mp4_writer_roundtrip(tmp_path):
     from scenedreamer_amd.output import FrameWriter, to_uint8_hwc
     yy, xx = torch.meshgrid(torch.linspace(-1, 1, 48), torch.linspace(-1, 1, 64), indexing="ij")
     frames = [torch.stack([torch.sin(3 * xx + k), torch.cos(2 * yy - k), xx * yy])[None] for k in range(7)]
-    w = FrameWriter(str(tmp_path / "png"), fmt="png", video_path=str(tmp_path / "out.mp4"), fps=10)
+    w = FrameWriter(str(tmp_path / "png"), fmt="png", video_path=str(tmp_path / "out.mp4"), fps=10, video_backend="mjpeg")
     for i, f in enumerate(frames):
         w.submit(f, i)
     w.close()
@@ -270,7 +270,7 @@ def test_mp4_writer_strided_and_late_indices_stay_bounded(tmp_path):
     from scenedreamer_amd.output import FrameWriter
     yy, xx = torch.meshgrid(torch.linspace(-1, 1, 32), torch.linspace(-1, 1, 48), indexing="ij")
     frames = [torch.stack([torch.sin(3 * xx + k), torch.cos(2 * yy - k), xx * yy])[None] for k in range(24)]
-    w = FrameWriter(None, video_path=str(tmp_path / "out.mp4"), fps=10, depth=4)
+    w = FrameWriter(None, video_path=str(tmp_path / "out.mp4"), fps=10, depth=4, video_backend="mjpeg")
     order = [8 * i + 3 for i in range(20)] + [2, 500, 499, 501]
     for i, idx in enumerate(order):
         w.submit(frames[i], idx)

@@ -93,14 +93,24 @@ def test_full_frame_equals_reference_tiling(renderer, weights_full, scene256, lu
 
 
 def test_minimal_apron_is_bit_identical(renderer, scene256):
-    """Evaluating the field / CNN on the 4-px apron the image can depend on == evaluating the reference's 15-px apron."""
+    """Evaluating the field / CNN on the 4-px apron the image can depend on == evaluating the reference's 15-px apron: the same
+    bits when every sample is evaluated (term_eps = 0).  With early ray termination (the default) WHICH 32 consecutive rays
+    share a group -- and stop together -- depends on the window, so the two agree to the termination bound instead."""
     from scenedreamer_amd import camera
-    for pi, hw in ((1, (96, 80)), (6, (61, 133))):
-        pose = camera.eval_camera_poses(scene256, maxstep=8)[pi]
-        a = renderer.render_frame(pose, hw, 12, mode="fused", apron="minimal")
-        b = renderer.render_frame(pose, hw, 12, mode="fused", apron="reference")
-        assert a.shape == b.shape == (1, 3, hw[0], hw[1])
-        assert torch.equal(a, b)
+    try:
+        for eps, same in ((0.0, True), (None, False)):
+            renderer.set_precision(term_eps=eps)
+            for pi, hw in ((1, (96, 80)), (6, (61, 133))):
+                pose = camera.eval_camera_poses(scene256, maxstep=8)[pi]
+                a = renderer.render_frame(pose, hw, 12, mode="fused", apron="minimal")
+                b = renderer.render_frame(pose, hw, 12, mode="fused", apron="reference")
+                assert a.shape == b.shape == (1, 3, hw[0], hw[1])
+                if same:
+                    assert torch.equal(a, b)
+                else:
+                    assert float((a - b).abs().max()) < 2e-4
+    finally:
+        renderer.set_precision()
 
 
 def test_ray_chunking_is_bit_identical(renderer, scene256, monkeypatch):
