@@ -278,7 +278,8 @@ def dropin_record(args, weights, scene, dev):
                      "when the loop hands the frame to its video writer (after its own D2H copy + uint8 conversion); the first "
                      "call with 3 frames is the warm-up; PNG / MP4 encoders are no-ops"}
     with tempfile.TemporaryDirectory() as tmp, torch.no_grad():
-        for tile in (128, 1024):
+        for tile, coalesce in ((128, True), (128, False), (1024, True)):
+            dropin.binding(G).coalesce = coalesce
             kw = dict(camera_mode=0, num_samples=args.samples, tile_size=tile, resolution_hw=hw, cam_ang=72)
             G.inference_givenstyle(style, os.path.join(tmp, f"warm{tile}"), cam_maxstep=3, **kw)
             torch.cuda.synchronize()
@@ -292,9 +293,13 @@ def dropin_record(args, weights, scene, dev):
             n = len(stamps)
             fps = (n - 1) / (stamps[-1] - stamps[0]) if n > 1 else None
             tiles = ((hw[0] + tile - 1) // tile) * ((hw[1] + tile - 1) // tile)
-            out["runs"].append({"tile_size": tile, "tiles_per_frame": tiles, "frames": n, "frames_per_s": fps,
+            out["runs"].append({"tile_size": tile, "tiles_per_frame": tiles, "frame_evaluated_once_for_its_tiles": bool(coalesce and tiles > 1),
+                                "frames": n, "frames_per_s": fps,
                                 "ms_per_frame": 1000.0 / fps if fps else None, "whole_call_s": t1 - t0,
-                                "note": ("the reference's default tiling (inference.py passes no tile_size)" if tile == 128 else
+                                "note": (("the reference's default tiling (inference.py passes no tile_size)" +
+                                          ("; the binding evaluates the whole frame when its first tile arrives and serves the 40 tiles as views"
+                                           if coalesce else "; every tile evaluated by its own field / CNN launches (binding.coalesce = False)"))
+                                         if tile == 128 else
                                          "tile_size >= frame -- an argument of the unmodified method: one _forward_perpix / "
                                          "_forward_global call per frame"),
                                 "calls": {k: v - before[k] for k, v in b.stats.items() if k != "why"}, "reference_path_reasons": dict(b.stats["why"])})

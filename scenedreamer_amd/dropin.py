@@ -18,6 +18,13 @@ the float tolerance of the native kernels (1e-3 abs, tests/test_dropin_gpu.py). 
 `_forward_perpix_reference` / `_forward_global_reference`), which then runs on the module-level drop-ins (modules.py) and
 the HIP ops -- never on a CPU path.  `binding(G).stats` counts which way every call went and why.
 
+Tiles: inference_givenstyle evaluates a frame in overlapping tiles (its default: 40 tiles of 158 x 158 rays for 960x540).
+The per-pixel field has no coupling between rays and the CNN's receptive radius (4 px) is below the 15 px the loop crops off
+every inner tile edge, so the binding evaluates the WHOLE frame once -- one field launch, one CNN pass -- when the first tile
+of a frame arrives, and serves the frame's tiles as views of that result (GeneratorBinding.frame_field / frame_image_tile;
+`binding(G).coalesce = False` evaluates tile by tile, in place, instead).  A frame is recognised through object identities of
+the sky pre-pass / camera tensors and the version counters of the frame arrays, never through bare addresses.
+
 _forward_perpix returns the reference's 12-tuple.  `net_out` is always there.  With `aux=False` (default: the inference
 loop and Generator.forward only read `net_out`) the other eleven are None; with `aux=True` new_dists, weights,
 total_weights_raw, rand_depth, sky_mask, sky_only_mask and new_idx are produced as well (what inference_givenstyle_depth
@@ -44,9 +51,11 @@ class GeneratorBinding:
         self.B = modules.Backend()
         self.aux = bool(aux)
         self.stats = {"perpix_fast": 0, "perpix_reference": 0, "global_fast": 0, "global_reference": 0, "tiles_in_place": 0,
-                      "tiles_copied": 0, "sky_reused": 0, "sky_evaluated": 0, "why": {}}
+                      "tiles_copied": 0, "sky_reused": 0, "sky_evaluated": 0, "frames_coalesced": 0, "tiles_from_frame": 0,
+                      "cnn_tiles_from_frame": 0, "why": {}}
         self._scene_key = None
-        self._lut_src = None
+        self._frame = None          # the frame evaluated once for all of its tiles (frame_field)
+        self.coalesce = True
 
     # ------------------------------------------------------------------ what the fused kernel implements
     def why_not_perpix(self, G, voxel_id, depth2, raydirs, cam_ori_t, z, global_enc):
@@ -165,7 +174,7 @@ class GeneratorBinding:
                     last["wkey"] == modules.Backend.tensors_key(G.sky_net)):
                 self.stats["tiles_in_place"] += 1
                 self.stats["sky_reused"] += 1
-                return win, pv, pd, pr, last["sky_c"], None
+                return win, pv, pd, pr, last["sky_c"], last
         n = h * w
         vid = voxel_id.reshape(n, M).contiguous()
         d2 = depth2.reshape(2, n, M).contiguous()
@@ -174,6 +183,62 @@ class GeneratorBinding:
         self.stats["tiles_copied"] += 1
         self.stats["sky_evaluated"] += 1
         return fused.Window(n), vid, d2, rd, sky_c, sky_mean
+
+    # ------------------------------------------------------------------ one field / CNN evaluation per FRAME
+    def frame_field(self, G, last, win, bases, views, cam_ori_t, sky_avg, ns):
+        """net_out [1,H0,W0,64] of the WHOLE frame the tile belongs to, evaluated once and kept for the frame's other tiles.
+
+        inference_givenstyle cuts the padded frame into overlapping tiles (128 px + a 30-px apron, scenedreamer.py:600-616) and
+        calls _forward_perpix per tile: 828 000 tile-rays for the 564 300 rays of a 960x540 frame, in 40 launches that each fill
+        the GPU for a few rounds.  _forward_perpix is a per-ray function of the frame-wide arrays (no coupling between rays), so
+        a tile's result IS the tile-shaped window of the frame's result: the first tile of a frame evaluates all rays in one
+        launch, the others are views of it.  What identifies "the same frame" are object identities held here (the sky
+        pre-pass record, the camera tensor) plus the version counters of the three frame arrays -- never bare addresses, which
+        the caching allocator reuses from frame to frame."""
+        fr = self._frame
+        key = (bases, tuple(v._version for v in views), cam_ori_t._version, ns, self.B._zkey.get("render_net."), self._scene_key,
+               self.B._bound["render_net."][1], float(self.B.sample_depth), float(self.B.dists_scale), int(self.B.M))
+        if (fr is not None and fr["last"] is last and fr["cam"] is cam_ori_t and fr["sky_avg"] is sky_avg and fr["key"] == key):
+            return fr["net_out"]
+        H0, W0 = win.n_src // win.pitch, win.pitch
+        net_out = fused.field_render(self.B, bases[0], bases[1], bases[2], cam_ori_t, last["sky_c"], sky_avg, ns,
+                                     window=fused.Window(win.n_src))
+        self._frame = dict(last=last, cam=cam_ori_t, sky_avg=sky_avg, key=key, net_out=net_out.view(1, H0, W0, 64), img=None, raw=None,
+                           keep=views)
+        self.stats["frames_coalesced"] += 1
+        return self._frame["net_out"]
+
+    def frame_image_tile(self, G, net_out, z):
+        """If `net_out` is a tile-shaped view of the frame evaluated by frame_field, the same window of the frame's image
+        (MfmaCNN on the whole frame, once): RenderCNN's receptive radius is 4 px and the reference crops 15 px off every tile
+        edge that is not a frame edge (scenedreamer.py:623-624), so every pixel it keeps is the pixel of the frame-wide
+        evaluation.  None if net_out is something else."""
+        fr = self._frame
+        if fr is None or net_out.dim() != 4:
+            return None
+        full = fr["net_out"]
+        _, H0, W0, _ = full.shape
+        _, h, w, c = net_out.shape
+        if (net_out.untyped_storage().data_ptr() != full.untyped_storage().data_ptr() or c != 64 or net_out._version != full._version or
+                (w > 1 and net_out.stride(2) != 64) or (h > 1 and net_out.stride(1) != W0 * 64) or net_out.stride(3) != 1):
+            return None
+        off = net_out.storage_offset() - full.storage_offset()
+        if off < 0 or off % 64:
+            return None
+        hb, wb = divmod(off // 64, W0)
+        if hb + h > H0 or wb + w > W0:
+            return None
+        B = self.B
+        zkey = (z.data_ptr(), z._version)
+        if fr["img"] is None or fr.get("img_key") != (zkey, B._bound.get("denoiser.", (None, None))[1]):
+            B.bind("denoiser.", G.denoiser)
+            B.style("denoiser.", z, 0, fold_denoiser)
+            raw = torch.empty((1, 3, H0, W0), dtype=torch.float32, device=full.device)
+            fr["img"] = B.mfma_cnn(full)(full, raw=raw)
+            fr["raw"] = raw
+            fr["img_key"] = (zkey, B._bound["denoiser."][1])
+        self.stats["cnn_tiles_from_frame"] += 1
+        return fr["img"][:, :, hb:hb + h, wb:wb + w], fr["raw"][:, :, hb:hb + h, wb:wb + w]
 
 
 def _render_net_reason(net):
@@ -230,13 +295,21 @@ def fast_forward_perpix(self, blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z
         if hasattr(self, "sky_avg"):                          # the frame-wide pre-pass of inference_givenstyle, :592-598
             sky_avg = self.sky_avg
         else:                                                 # sky_global_avgpool over the rays of this call, :392-393
-            sky_avg = sky_mean if sky_mean is not None else sky_c.mean(dim=0)
+            sky_avg = sky_mean if isinstance(sky_mean, torch.Tensor) else sky_c.mean(dim=0)
         u = None
         if not self.coarse_deterministic_sampling:            # the reference's draw, mc_utils.py:121 (nsamples = num_samples + 1)
             u = torch.rand([1, h, w, ns + 1, 1], dtype=depth2.dtype, device=depth2.device).reshape(h * w, ns + 1)
         aux = {} if b.aux else None
-        net_out = fused.field_render(B, vid, d2, rd, cam_ori_t, sky_c, sky_avg, ns, u=u, window=win, aux=aux)
         out = [None] * len(PERPIX_OUTPUTS)
+        if (b.coalesce and isinstance(sky_mean, dict) and u is None and aux is None and hasattr(self, "sky_avg") and
+                win.rows * win.cols < win.n_src):
+            # a tile of a frame whose arrays (and sky features) are all at hand: the frame is evaluated once, tiles are views
+            full = b.frame_field(self, sky_mean, win, (vid, d2, rd), (voxel_id, depth2, raydirs), cam_ori_t, sky_avg, ns)
+            hb, wb = divmod(win.first, win.pitch)
+            out[0] = full[:, hb:hb + h, wb:wb + w, :]
+            b.stats["tiles_from_frame"] += 1
+            return tuple(out)
+        net_out = fused.field_render(B, vid, d2, rd, cam_ori_t, sky_c, sky_avg, ns, u=u, window=win, aux=aux)
         out[0] = net_out.view(1, h, w, 64)
         if aux is not None:
             # the same values the reference returns (scenedreamer.py:335-352, :373-377); samples come from the stand-alone op
@@ -272,6 +345,10 @@ def fast_forward_global(self, net_out, z):
     _count(b, "global_fast")
     B = b.B
     with torch.no_grad():
+        if b.coalesce:
+            got = b.frame_image_tile(self, net_out, z)
+            if got is not None:
+                return got
         B.bind("denoiser.", den)
         B.style("denoiser.", z, 0, fold_denoiser)
         x = net_out.contiguous()

@@ -268,22 +268,28 @@ def test_unsupported_calls_fall_to_the_reference_method_on_hip_ops(scene256, wei
 
 
 @pytest.mark.needs_reference
-@pytest.mark.parametrize("tile", [64, 1024])
-def test_unmodified_inference_loop_on_the_fused_kernels(scene256, weights_full, tmp_path, tile):
+@pytest.mark.parametrize("tile,coalesce", [(64, True), (64, False), (1024, True)])
+def test_unmodified_inference_loop_on_the_fused_kernels(scene256, weights_full, tmp_path, tile, coalesce):
     """Generator.inference_givenstyle (scenedreamer.py:479-632), UNCHANGED, with install_shims(fast=True): 2 x 2 tiles (tile_size
-    64: every tile read in place from the frame arrays, sky features of the pre-pass reused) and one tile per frame (tile_size >=
-    frame) -- against this package's renderer on the same trajectory: uint8 frames agree to one level."""
+    64) -- the frame evaluated ONCE when its first tile arrives and the tiles served as views of it (coalesce), or every tile
+    evaluated in place from the frame arrays with the sky features of the pre-pass reused -- and one tile per frame (tile_size >=
+    frame); against this package's renderer on the same trajectory: uint8 frames agree to one level."""
     from loop_helpers import run_reference_loop
     from scenedreamer_amd import camera, dropin, synth
     from scenedreamer_amd.output import to_uint8_hwc
     from scenedreamer_amd.renderer import Renderer
     G, _ = _generator(weights_full, scene256, fast=True)
     hw, ns, steps = [72, 104], 12, 3
-    frames = run_reference_loop(G, str(tmp_path / "ref"), hw, ns, steps, tile_size=tile)
     b = dropin.binding(G)
+    b.coalesce = coalesce
+    frames = run_reference_loop(G, str(tmp_path / "ref"), hw, ns, steps, tile_size=tile)
     tiles = 4 if tile == 64 else 1
     assert b.stats["perpix_fast"] == steps * tiles and b.stats["perpix_reference"] == 0 and b.stats["global_fast"] == steps * tiles, b.stats
     assert b.stats["tiles_in_place"] == steps * tiles and b.stats["sky_reused"] == steps * tiles, b.stats
+    if tile == 64 and coalesce:
+        assert b.stats["frames_coalesced"] == steps and b.stats["tiles_from_frame"] == b.stats["cnn_tiles_from_frame"] == steps * tiles, b.stats
+    else:
+        assert b.stats["frames_coalesced"] == b.stats["tiles_from_frame"] == b.stats["cnn_tiles_from_frame"] == 0, b.stats
     R = Renderer(weights_full, scene256, "cuda")
     R.set_style(synth.make_style(8888))
     poses = camera.eval_camera_poses(scene256, maxstep=steps, pattern=0, cam_ang=72)
@@ -293,7 +299,7 @@ def test_unmodified_inference_loop_on_the_fused_kernels(scene256, weights_full, 
         d = np.abs(frames[f].astype(np.int32) - mine)
         assert frames[f].shape == mine.shape == (hw[0], hw[1], 3) and frames[f].std() > 5
         worst, off = max(worst, int(d.max())), max(off, float((d > 0).mean()))
-    print(f"inference_givenstyle (unmodified, fast shims, tile_size {tile}) vs scenedreamer_amd frames: max |diff| {worst} level, "
+    print(f"inference_givenstyle (unmodified, fast shims, tile_size {tile}, coalesce {coalesce}) vs scenedreamer_amd frames: max |diff| {worst} level, "
           f"{100 * off:.2f} % of the values differ; stats {b.stats}")
     assert worst <= 1 and off < 0.2
     assert os.path.exists(os.path.join(str(tmp_path / "ref"), "rgb_render", "00002.png"))
