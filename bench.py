@@ -754,7 +754,7 @@ def main():
                        "dist_backend": (args.backend + (f", {world} ranks on {ndev} GPU(s)" if world > ndev else "")) if world > 1 else None,
                        "apron_note": "ray casting and the sky MLP always cover the reference's padded frame (15-px apron); "
                                      "'minimal' evaluates the field MLP and the CNN on the 4-px apron that can reach a kept "
-                                     "pixel -- the same image: bit-identical with term_eps = 0, within the early-termination bound (< 2e-4) otherwise "
+                                     "pixel -- the same image: bit-identical with term_eps = 0, within the early-termination bound (2 eps = 1e-4 on net_out each) otherwise "
                                      "(tests/test_render_gpu.py, test_fullsize_gpu.py)"},
             "frame_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "delivered_frames_per_s_uint8_host": delivered_fps,
             "stage_ms": stage_ms, "setup_s": setup_s, "broadcast": bstats or None, f"ms_per_step_apron_{other}": other_ms,

@@ -682,7 +682,7 @@ class Renderer:
         sky MLP still sees every ray of the padded frame, because its frame mean does (scenedreamer.py:592-598).  The
         image is bit-identical to "reference" (full apron) when every sample is evaluated (term_eps = 0); with early ray
         termination (the default) the 32-ray groups that stop together differ between the two windows, and the images agree
-        to the termination bound (< 2e-4) -- tests/test_render_gpu.py."""
+        to the termination bound (each net_out within 2 eps = 1e-4 of the untruncated one) -- tests/test_render_gpu.py."""
         ev = _Stamps(timers)
         with torch.no_grad():
             ev.mark("start")

@@ -107,8 +107,8 @@ def test_minimal_apron_is_bit_identical(renderer, scene256):
                 assert a.shape == b.shape == (1, 3, hw[0], hw[1])
                 if same:
                     assert torch.equal(a, b)
-                else:
-                    assert float((a - b).abs().max()) < 2e-4
+                else:       # each evaluation is within 2 eps = 1e-4 of the untruncated net_out; the CNN passes that on with gain ~1
+                    assert float((a - b).abs().max()) < 5e-4
     finally:
         renderer.set_precision()
 
