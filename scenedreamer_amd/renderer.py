@@ -199,10 +199,22 @@ class Renderer:
         depth = torch.gather(heads, 1, idx) + mid
         return depth, nd, idx
 
-    def field_unfused(self, voxel_id, depth2, raydirs, cam_ori, sky_c, sky_avg, ns):
-        """Per-ray feature net_out [R,64] from [R,M] intersections (scenedreamer.py:313-430)."""
+    def field_unfused(self, voxel_id, depth2, raydirs, cam_ori, sky_c, sky_avg, ns, placement="torch"):
+        """Per-ray feature net_out [R,64] from [R,M] intersections (scenedreamer.py:313-430).
+        placement: "torch" = sample placement by PyTorch ops on the GPU, what the unmodified reference does on the op shims
+        (torch.cumsum accumulates in float32 on the GPU, in double on the CPU: the two reference paths place some samples 1 ulp
+        apart, which the fine grid levels and the density head turn into net_out differences of a few 1e-4 at isolated rays);
+        "kernel" = placement by sdn_sample_depth, the device function the fused kernel uses (the CPU reference's arithmetic) -- the
+        fp32 twin calibrate_style compares with, so that what it measures is the reduced-precision ARITHMETIC of the fused path
+        and not the reference's own placement chaos."""
         w = self.w
-        depth, nd, idx = self.place_samples(depth2, ns)
+        if placement == "kernel":
+            R_ = depth2.shape[1]
+            depth, nd, idx = ops.sample_depth_batched(depth2.reshape(2, R_, 1, self.M, 1).unsqueeze(0).contiguous(), ns + 1, deterministic=True,
+                                                      use_box_boundaries=False, sample_depth=self.sample_depth)
+            depth, nd, idx = depth.reshape(R_, ns), nd.reshape(R_, ns), idx.reshape(R_, ns).clamp(max=self.M - 1)
+        else:
+            depth, nd, idx = self.place_samples(depth2, ns)
         depth = torch.where(torch.isnan(depth) | torch.isinf(depth), torch.zeros_like(depth), depth)
         wc = raydirs[:, None, :] * depth[:, :, None] + cam_ori[None, None, :]
         lab = torch.gather(self.lut[voxel_id.long()], 1, idx)
@@ -271,7 +283,8 @@ class Renderer:
         """Measure END TO END, for the CURRENT weights and style, what the reduced-precision choices of the fused path cost, and
         decide.  One frame (`pose`; at most CAL_MAX_PIXELS pixels -- a larger frame is calibrated at a reduced resolution) is
         rendered by the reference's op sequence in fp32 (field_unfused + render_cnn: PyTorch fp32 + the drop-in HIP ops -- the
-        path the CPU-oracle tests validate) and by the candidates; the cheapest candidate inside the bounds is adopted:
+        path the CPU-oracle tests validate; samples placed by the fused kernel's own device function, see field_unfused) and by
+        the candidates; the cheapest candidate inside the bounds is adopted:
 
           colour layers fc_5 / fc_6: f16 + MX-fp6 corrections (colour_terms 6) if net_out stays within COLOUR_AUTO_BOUND of the
             3-term evaluation, else the 3-term split;
@@ -301,8 +314,9 @@ class Renderer:
             sky32 = self.sky_features(rd)
             savg32 = sky32.mean(dim=0, keepdim=True)
             ori_dev = ori.to(self.dev)
-            ref_no = torch.cat([self.field_unfused(vid[r:r + CAL_CHUNK], d2[:, r:r + CAL_CHUNK], rd[r:r + CAL_CHUNK], ori_dev,
-                                                   sky32[r:r + CAL_CHUNK], savg32, num_samples) for r in range(0, n, CAL_CHUNK)], dim=0)
+            ref_no = torch.cat([self.field_unfused(vid[r:r + CAL_CHUNK], d2[:, r:r + CAL_CHUNK].contiguous(), rd[r:r + CAL_CHUNK], ori_dev,
+                                                   sky32[r:r + CAL_CHUNK], savg32, num_samples, placement="kernel")
+                                for r in range(0, n, CAL_CHUNK)], dim=0)
             ref_img = inner(self.render_cnn(ref_no.view(1, H0, W0, 64)))
             # ---- the fused field
             sky_c, sky_avg = fused.sky_fused(self, rd)
