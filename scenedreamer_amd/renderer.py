@@ -841,45 +841,88 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
     # frame's CNN has been enqueued, i.e. beside this frame's field kernel; "late" = behind this frame's field kernel, i.e. beside
     # its CNN.  (SDN_FRONT=late|early; measured in DESIGN.md section 6.)
     late = deep and os.environ.get("SDN_FRONT", FRONT_DEFAULT) == "late"
+    # The render CNN of frame i on a THIRD stream, beside the field kernel of frame i+1 (SDN_CNN_STREAM=1): both are one-workgroup-
+    # per-CU kernels, so they cannot share a CU, but the CNN's six dependent launches leave CUs idle at every launch boundary
+    # and the field kernel's persistent workgroups retire over the length of a 32-ray group -- with both in flight whichever has
+    # workgroups ready takes the idle CUs.  The image of frame i is handed out one iteration later (after the field kernel of
+    # frame i+1 has been enqueued), so the consumer's wait for it does not order the main stream behind the CNN.
+    cnn_side = deep and os.environ.get("SDN_CNN_STREAM", CNN_STREAM_DEFAULT) == "1" and getattr(self, "field_gate", None) is not None
+    cstream = None
+    if cnn_side:
+        cstream = getattr(self, "_cnn_stream", None)
+        if cstream is None:
+            cstream = self._cnn_stream = torch.cuda.Stream(self.dev)
+    pending = None          # (image, its completion event) of the previous frame
     nxt = front(poses[0], 0)
-    for i, pose in enumerate(poses):
-        cur, done = nxt
-        if not late:
-            nxt = front(poses[i + 1], (i + 1) & 1) if i + 1 < len(poses) else None
-        main.wait_event(done)
-        if not deep:
-            yield self.render_frame(pose, resolution_hw, num_samples, mode=mode, apron=apron, _precast=cur, **kw)
-            continue
-        buf, sky_c, sky_avg, win = cur
-        with torch.no_grad():
-            if probe is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(main)
-            if one:
-                net_out = fused.field_render(self, *buf, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, num_samples,
-                                             window=win).view(1, Hp, Wp, 64)
-            else:
-                net_out = fused.mlp_from(self, buf, sky_c, sky_avg.reshape(-1), win.n_rays, num_samples, window=win).view(1, Hp, Wp, 64)
-            if probe is not None:
-                e1.record(main)
-                probe.setdefault("mlp_kernel", []).append((e0, e1))
-            if late:
+    try:
+        for i, pose in enumerate(poses):
+            cur, done = nxt
+            if not late:
                 nxt = front(poses[i + 1], (i + 1) & 1) if i + 1 < len(poses) else None
-            cnn = self.mfma_cnn(net_out)         # (first frame of a style: calibrates the 3x3 precision, see mfma_cnn)
-            if probe is not None:
-                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                c0.record(main)
-            img = cnn(net_out)
-            if probe is not None:
-                c1.record(main)
-                probe.setdefault("render_cnn", []).append((c0, c1))
-            c = crop - o
-            yield img[:, :, c:-c, c:-c] if c else img
+            main.wait_event(done)
+            if not deep:
+                yield self.render_frame(pose, resolution_hw, num_samples, mode=mode, apron=apron, _precast=cur, **kw)
+                continue
+            buf, sky_c, sky_avg, win = cur
+            with torch.no_grad():
+                if probe is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(main)
+                if one:
+                    net_out = fused.field_render(self, *buf, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, num_samples,
+                                                 window=win).view(1, Hp, Wp, 64)
+                else:
+                    net_out = fused.mlp_from(self, buf, sky_c, sky_avg.reshape(-1), win.n_rays, num_samples, window=win).view(1, Hp, Wp, 64)
+                if probe is not None:
+                    e1.record(main)
+                    probe.setdefault("mlp_kernel", []).append((e0, e1))
+                if late:
+                    nxt = front(poses[i + 1], (i + 1) & 1) if i + 1 < len(poses) else None
+                c = crop - o
+                if cnn_side:
+                    f_done = torch.cuda.Event()
+                    f_done.record(main)
+                    net_out.record_stream(cstream)              # allocated on the main stream, read on the CNN stream
+                    with torch.cuda.stream(cstream):
+                        cstream.wait_event(f_done)
+                        cnn = self.mfma_cnn(net_out)            # (decided by calibrate_style: no calibration launches here)
+                        if probe is not None:
+                            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            c0.record(cstream)
+                        img = cnn(net_out)
+                        if probe is not None:
+                            c1.record(cstream)
+                            probe.setdefault("render_cnn", []).append((c0, c1))
+                        c_done = torch.cuda.Event()
+                        c_done.record(cstream)
+                    img.record_stream(main)                     # allocated on the CNN stream, consumed on the main stream
+                    if pending is not None:
+                        main.wait_event(pending[1])
+                        yield pending[0]
+                    pending = (img[:, :, c:-c, c:-c] if c else img, c_done)
+                    continue
+                cnn = self.mfma_cnn(net_out)         # (first frame of a style: calibrates the 3x3 precision, see mfma_cnn)
+                if probe is not None:
+                    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    c0.record(main)
+                img = cnn(net_out)
+                if probe is not None:
+                    c1.record(main)
+                    probe.setdefault("render_cnn", []).append((c0, c1))
+                yield img[:, :, c:-c, c:-c] if c else img
+        if pending is not None:
+            last, pending = pending, None
+            main.wait_event(last[1])
+            yield last[0]
+    finally:
+        if pending is not None:      # the consumer stopped early: the main stream still has to be ordered behind the CNN stream's work
+            main.wait_event(pending[1])
 
 
 Renderer.render_frames = _render_frames
 
 FRONT_DEFAULT = "early"
+CNN_STREAM_DEFAULT = "0"   # render CNN of frame i on its own stream beside the field kernel of frame i+1 (see _render_frames)
 CNN_AUTO_BOUND = 5e-4   # mfma_cnn: largest image difference (max abs) at which the 1-term 3x3 convolutions are accepted
 CNN_CAL_PIXELS = 400_000   # ... measured on every net_out of a style until this many pixels have been compared
 IMAGE_BUDGET = 8e-4        # ... and only while (field error charged) + (that difference) stays below this (north star: 1e-3)

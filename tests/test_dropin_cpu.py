@@ -151,3 +151,31 @@ def test_import_hook_patches_the_unmodified_reference_package():
         RH.install("oracle")      # leave the process as the other CPU tests expect it
         for name in [n for n in sys.modules if n.split(".")[0] == "imaginaire"]:
             del sys.modules[name]
+
+
+def test_frame_image_tile_maps_tile_views_of_the_cached_frame():
+    """GeneratorBinding.frame_image_tile: a tile-shaped VIEW of the frame's cached net_out is answered with the same window of
+    the frame's image; a copy, a strided view or an unrelated tensor is not (the per-tile CNN path serves those)."""
+    from scenedreamer_amd.dropin import GeneratorBinding
+    b = GeneratorBinding()
+    H0, W0 = 23, 31
+    full = torch.arange(H0 * W0 * 64, dtype=torch.float32).reshape(1, H0, W0, 64)
+    img = torch.arange(3 * H0 * W0, dtype=torch.float32).reshape(1, 3, H0, W0)
+    b._frame = dict(net_out=full, img=img, raw=img + 0.5, img_key=None)
+    z = torch.zeros(1, 4)
+
+    class _G:
+        denoiser = None
+    b._frame["img_key"] = ((z.data_ptr(), z._version), None)      # the image of this style is already there: no CNN call
+    for hb, he, wb, we in ((0, 14, 0, 14), (8, 23, 16, 31), (3, 4, 5, 31), (0, 23, 30, 31)):
+        tile = full[:, hb:he, wb:we, :]
+        got = b.frame_image_tile(_G, tile, z)
+        assert got is not None, (hb, he, wb, we)
+        assert torch.equal(got[0], img[:, :, hb:he, wb:we]) and torch.equal(got[1], img[:, :, hb:he, wb:we] + 0.5)
+    assert b.stats["cnn_tiles_from_frame"] == 4
+    assert b.frame_image_tile(_G, full[:, 2:9, 3:9, :].clone(), z) is None              # a copy: another storage
+    assert b.frame_image_tile(_G, full[:, ::2, :, :], z) is None                         # strided rows
+    assert b.frame_image_tile(_G, full[:, :, :, :32], z) is None                         # not 64 features
+    assert b.frame_image_tile(_G, torch.zeros(1, 4, 4, 64), z) is None
+    b._frame = None
+    assert b.frame_image_tile(_G, full[:, :4, :4, :], z) is None
