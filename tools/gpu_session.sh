@@ -5,6 +5,7 @@
 #   new        the tests added in round 4 (drop-in surface, precision gates)
 #   core       render / fused / ops / dist tests
 #   full       the whole `-m gpu` suite
+#   smoke      __graft_entry__.smoke()
 #   bench      bench.py headline (20 steps) without the CPU leg
 #   benchfull  bench.py exactly as the driver runs it (defaults)
 #   dropin     bench.py --only dropin
@@ -22,6 +23,7 @@ for step in "$@"; do
     new)   timeout 1500 python -m pytest tests/test_dropin_gpu.py tests/test_precision_gates_gpu.py -q -m gpu -s --durations=10 > gpurun_out/${label}_new.log 2>&1; echo "rc=$?"; tail -25 gpurun_out/${label}_new.log ;;
     core)  timeout 1500 python -m pytest tests/test_render_gpu.py tests/test_fused_gpu.py tests/test_ops_gpu.py tests/test_dist_gpu.py -q -m gpu --durations=10 > gpurun_out/${label}_core.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/${label}_core.log ;;
     full)  timeout 2400 python -m pytest tests -q -m gpu -s --durations=25 > gpurun_out/${label}_full.log 2>&1; echo "rc=$?"; tail -40 gpurun_out/${label}_full.log ;;
+    smoke) timeout 600 python __graft_entry__.py smoke > gpurun_out/${label}_smoke.log 2>&1; echo "rc=$?"; grep "\[smoke\]" gpurun_out/${label}_smoke.log ;;
     bench) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${label}_bench.json 2> gpurun_out/${label}_bench.err; echo "rc=$?"; tail -c 1500 gpurun_out/${label}_bench.json; tail -5 gpurun_out/${label}_bench.err ;;
     benchfull) timeout 900 python bench.py > gpurun_out/${label}_benchfull.json 2> gpurun_out/${label}_benchfull.err; echo "rc=$?"; tail -c 3000 gpurun_out/${label}_benchfull.json; tail -5 gpurun_out/${label}_benchfull.err ;;
     dropin) timeout 900 python bench.py --only dropin > gpurun_out/${label}_dropin.json 2> gpurun_out/${label}_dropin.err; echo "rc=$?"; tail -c 3000 gpurun_out/${label}_dropin.json; tail -8 gpurun_out/${label}_dropin.err ;;
