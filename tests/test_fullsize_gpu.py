@@ -104,10 +104,19 @@ def test_pipelined_trajectory_equals_frame_by_frame(big):
 
 
 def test_minimal_apron_is_bit_identical_at_full_size(big):
+    """The same bits when every sample is evaluated; with early ray termination (the default) the 32-ray groups that stop
+    together differ between the two windows: agreement to the termination bound (tests/test_render_gpu.py has the small case)."""
     R, scene, poses = big
+    try:
+        R.set_precision(term_eps=0.0)
+        a = R.render_frame(poses[9], (540, 960), 24, mode="fused", apron="minimal")
+        b = R.render_frame(poses[9], (540, 960), 24, mode="fused", apron="reference")
+        assert torch.equal(a, b)
+    finally:
+        R.set_precision()
     a = R.render_frame(poses[9], (540, 960), 24, mode="fused", apron="minimal")
     b = R.render_frame(poses[9], (540, 960), 24, mode="fused", apron="reference")
-    assert torch.equal(a, b)
+    assert float((a - b).abs().max()) < 5e-4
 
 
 @pytest.mark.parametrize("hw,ns,pi", [((540, 960), 24, 4), ((1080, 1920), 40, 12)])
