@@ -223,7 +223,9 @@ class SKYMLPNative:
                     # Generator._forward_perpix, which asks for sky_net of the very same rays again for every tile
                     # (scenedreamer.py:368-370 after the frame-wide pre-pass :592-598)
                     sky_c, _ = fused.sky_fused(B, rd)
-                    self.__dict__["_sdn_last_frame"] = dict(rd_ptr=rd.data_ptr(), rd_version=src[1], n_rays=per, sky_c=sky_c,
+                    # (rd_ref keeps the ray-direction storage alive: while this record exists its address cannot be handed to
+                    #  another tensor, so "same address + same version counter" below means "same content")
+                    self.__dict__["_sdn_last_frame"] = dict(rd_ref=src[0], rd_ptr=rd.data_ptr(), rd_version=src[1], n_rays=per, sky_c=sky_c,
                                                             zkey=B._zkey.get("sky_net."), wkey=B._bound["sky_net."][1])
                 else:
                     sky_c, _ = fused.sky_fused(B, x[i].reshape(per, 33), encoded=True)
