@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SDN_ABI_VERSION 2
+#define SDN_ABI_VERSION 3
 
 typedef void *sdn_stream_t; /* hipStream_t */
 
@@ -237,18 +237,27 @@ int sdn_field_mlp(const float *feat, const float *dist, const uint8_t *label, co
  * sky, outputs, schedule) with the same meaning; colour_terms 3 or 6.
  *   cam_ori_dev: NULL, or dev f32 [3] -- the camera origin read from device memory instead of cam_ori_host (which may then be
  *     NULL): Generator._forward_perpix receives it as the device tensor cam_ori_t (scenedreamer.py:313, :354).
- *   weights_out + depth_out (both or neither; term_eps must be 0): dev f32 [n_rays, num_samples], ZEROED by the caller -- the
- *     `weights` (volum_rendering_relu(...) * !sky_only, scenedreamer.py:373-376) and `rand_depth` (:346-352) return values of
- *     _forward_perpix, consumed by inference_givenstyle_depth (:812-817).  Samples of 32-ray groups without any hit are not
- *     visited: they keep the caller's zeros, which is their value. */
+ *   aux: NULL, or a host struct of optional device pointers (term_eps must be 0 when any is set) that receive the OTHER return
+ *     values of _forward_perpix (scenedreamer.py:429-430) for the rays of this launch (local ray index), so that a binding of
+ *     that method can return its whole 12-tuple: weights (:373-376; consumed by inference_givenstyle_depth, :812-817), depth =
+ *     rand_depth after the NaN / inf -> 0 replacement (:346-352), sigma = net_out_s and colour = net_out_c (LightningMLP's two
+ *     outputs, layers.py:114, :124), sky_blended = skynet_out_c after the keep_sky_out blend (:401), nosky = nosky_mask (:382).
+ *     With aux set no 32-ray group is skipped and rays that hit nothing are gathered too (the reference evaluates them). */
+typedef struct sdn_field_aux {
+    float *weights;      /* dev f32 [n_rays, num_samples]     */
+    float *depth;        /* dev f32 [n_rays, num_samples]     */
+    float *sigma;        /* dev f32 [n_rays, num_samples]     */
+    float *colour;       /* dev f32 [n_rays, num_samples, 64] */
+    float *sky_blended;  /* dev f32 [n_rays, 64]              */
+    uint8_t *nosky;      /* dev u8  [n_rays]                  */
+} sdn_field_aux;
 int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,
                      int32_t n_rays, int32_t max_blocks, int32_t num_samples, float sample_depth, float dists_scale,
                      const void *packed, const float *consts, const float *sky_c, const float *sky_avg, float *net_out,
                      int32_t colour_terms, float term_eps, uint8_t *passes, int32_t n_workgroups, const int32_t *window_host,
-                     int32_t strat_division, int32_t *ticket, const float *cam_ori_dev, float *weights_out, float *depth_out,
-                     sdn_stream_t stream);
+                     int32_t strat_division, int32_t *ticket, const float *cam_ori_dev, const sdn_field_aux *aux, sdn_stream_t stream);
 
 /* LightningMLP.forward as an op (imaginaire/model_utils/layers.py:92-126; the nn.Module boundary of SURVEY 8(b)) for N = 1:
  *   x dev f32 [n_rows, 128] hash-grid features; label dev u8 [n_rows] = index of the one in each row of the one-hot mask `m`

@@ -61,7 +61,7 @@ _SIGNATURES = {
                             ctypes.c_float, c_p, ctypes.c_int32, c_p, c_p, c_p, c_p]),
     "sdn_field_render": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
                                ctypes.c_int32, c_f, c_f, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, c_f, c_p, ctypes.c_int32, c_p,
-                               ctypes.c_int32, c_p, c_p, c_p, c_p, c_p]),
+                               ctypes.c_int32, c_p, c_p, c_p, c_p]),
     "sdn_render_mlp": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, ctypes.c_int32, ctypes.c_int32, c_p, c_p]),
     "sdn_sky_packed_weight_bytes": (ctypes.c_size_t, []),
     "sdn_sky_consts_floats": (ctypes.c_size_t, []),
@@ -91,6 +91,11 @@ class SdnError(RuntimeError):
     pass
 
 
+class FieldAux(ctypes.Structure):
+    """sdn_field_aux (include/sdnative.h): optional device pointers for the other return values of Generator._forward_perpix."""
+    _fields_ = [("weights", c_p), ("depth", c_p), ("sigma", c_p), ("colour", c_p), ("sky_blended", c_p), ("nosky", c_p)]
+
+
 def lib():
     """Return the loaded library, loading it on first use.  Raises if absent."""
     global _lib
@@ -108,7 +113,7 @@ def lib():
                     fn = getattr(L, name)  # AttributeError if the symbol is not exported
                     fn.restype = res
                     fn.argtypes = args
-                if L.sdn_abi_version() != 2:
+                if L.sdn_abi_version() != 3:
                     raise ImportError("libsdnative ABI version mismatch")
                 _lib = L
     return _lib

@@ -147,8 +147,13 @@ struct MlpParams {
     EncParams enc;             // FUSED (field_kernel): the encode stage's inputs; feat / dist / label / rayflag are unused then
     const float *cam_ori_dev;  // FUSED, optional dev f32 [3]: the camera origin read from device memory (overrides enc.ori): callers that hold
                                // it as a device tensor (Generator._forward_perpix's cam_ori_t) need no device -> host copy per call
-    float *w_out;              // MODE_FUSED_AUX: [R][ns] volume-rendering weight of every sample (weights * !sky_only, scenedreamer.py:373-376)
-    float *depth_out;          // MODE_FUSED_AUX: [R][ns] sample depths (rand_depth after the NaN / inf -> 0 replacement, :350-352)
+    // MODE_FUSED_AUX: the other return values of Generator._forward_perpix (scenedreamer.py:429-430), each optional
+    float *w_out;              // [R][ns]     weights: volume-rendering weight of every sample, * !sky_only (:373-376)
+    float *depth_out;          // [R][ns]     rand_depth after the NaN / inf -> 0 replacement (:350-352)
+    float *sig_out;            // [R][ns]     net_out_s: fc_sigma's output per sample (layers.py:114)
+    float *col_out;            // [R][ns][64] net_out_c: fc_out_c's output per sample (layers.py:124)
+    float *skyb_out;           // [R][64]     skynet_out_c after the keep_sky_out blend with sky_avg (:401)
+    uint8_t *nosky_out;        // [R]         nosky_mask (:382-383)
     float *sigma_out;          // MODE_RAW: [R] density fc_sigma(f) of every row (LightningMLP.forward's first output)
 };
 
@@ -1679,7 +1684,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         bool gnd = false;                                  // FUSED: any sample of the ray at world x <= 1 (:380)
         int drawn = grp_next + (int)gridDim.x;            // the group after next: static stride, or ...
         if (p.ticket && threadIdx.x == 0) drawn = 2 * (int)gridDim.x + atomicAdd(p.ticket, 1);   // ... the next undrawn one
-        const bool any_hit = __any(!(flag & 1));
+        // (AUX also returns the per-sample sigma / colour of rays that hit nothing -- the reference evaluates them -- so it skips no group)
+        const bool any_hit = AUX ? tile_ok : __any(!(flag & 1));
         // workgroup-uniform decisions: skip the group when none of its 32 rays hits anything; everybody learns the draw
         if (lane == 0) flags[wave] = any_hit ? 1 : 0;
         if (threadIdx.x == 0) flags[4] = drawn;
@@ -1740,7 +1746,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                 lab = es.label;
                 dist = es.dist;
                 if constexpr (AUX) smp_depth = es.depth;
-                const bool use_feat = !(flag & 1);
+                const bool use_feat = AUX ? ray_ok : !(flag & 1);
                 // 4 levels' gathers (64 x 16 B per lane) in flight at a time: two round trips per pass instead of eight
 #pragma unroll
                 for (int b = 0; b < 2; b++) {
@@ -1904,11 +1910,23 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             const float wgt = (1.f - __expf(-fe)) * __expf(-excl);
             carry += quad_dpp<QUAD_LAST>(incl);
             tsum += wgt;
-            if constexpr (AUX) {   // Generator._forward_perpix's `weights` (scenedreamer.py:373-376) and `rand_depth` (:346-352)
+            if constexpr (AUX) {   // the per-sample return values of Generator._forward_perpix
                 const int sidx = ch * SAMP_PER_STEP + q;
-                if (h == 0 && ray_ok && sidx < p.ns) {
-                    p.w_out[(size_t)ray * p.ns + sidx] = (flag & 1) ? 0.f : wgt;
-                    p.depth_out[(size_t)ray * p.ns + sidx] = smp_depth;
+                if (ray_ok && sidx < p.ns) {
+                    const size_t smp = (size_t)ray * p.ns + sidx;
+                    if (h == 0) {
+                        if (p.w_out) p.w_out[smp] = (flag & 1) ? 0.f : wgt;
+                        if (p.depth_out) p.depth_out[smp] = smp_depth;
+                        if (p.sig_out) p.sig_out[smp] = sigma;
+                    }
+                    if (p.col_out) {
+#pragma unroll
+                        for (int ib = 0; ib < 2; ib++)
+#pragma unroll
+                            for (int g4 = 0; g4 < 4; g4++)   // registers 4 g4 .. 4 g4 + 3 of row block ib = features 32 ib + 8 g4 + 4 h + e
+                                *reinterpret_cast<float4 *>(p.col_out + smp * OUTC + 32 * ib + 8 * g4 + 4 * h) =
+                                    make_float4(col[ib][4 * g4], col[ib][4 * g4 + 1], col[ib][4 * g4 + 2], col[ib][4 * g4 + 3]);
+                    }
                 }
             }
 #pragma unroll
@@ -1986,6 +2004,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     const float sky = nosky ? (scv[e] * 0.f + sav[e]) : scv[e];          // :401, mask in {0,1}
                     const float rgb_sky = fminf(fmaxf(sky, -1.f), 1.f) + 1.f;
                     o[e] = (sky_only ? 0.f : outq[ib][e]) + sky_w * rgb_sky - 1.f;       // :410-413
+                    if constexpr (AUX) {
+                        if (p.skyb_out) p.skyb_out[(size_t)ray * OUTC + f0 + e] = sky;
+                    }
+                }
+                if constexpr (AUX) {
+                    if (p.nosky_out && ib == 0 && q == 0 && h == 0) p.nosky_out[ray] = nosky ? 1 : 0;
                 }
                 *reinterpret_cast<float4 *>(p.net_out + (size_t)ray * OUTC + f0) = make_float4(o[0], o[1], o[2], o[3]);
             }
@@ -2888,6 +2912,7 @@ static int fill_mlp(MlpParams &p, const char *who, const void *packed, const flo
     p.term_depth = term_eps > 0.f ? -logf(term_eps) : 0.f;
     p.passes = passes;
     p.cam_ori_dev = nullptr; p.w_out = nullptr; p.depth_out = nullptr; p.sigma_out = nullptr;
+    p.sig_out = nullptr; p.col_out = nullptr; p.skyb_out = nullptr; p.nosky_out = nullptr;
     p.feat = nullptr; p.dist = nullptr; p.label = nullptr; p.rayflag = nullptr;
     p.wpk = (const half8 *)packed;
     p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
@@ -2957,10 +2982,10 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
                      int32_t num_samples, float sample_depth, float dists_scale, const void *packed, const float *consts,
                      const float *sky_c, const float *sky_avg, float *net_out, int32_t colour_terms, float term_eps, uint8_t *passes,
                      int32_t n_workgroups, const int32_t *window_host, int32_t strat_division, int32_t *ticket, const float *cam_ori_dev,
-                     float *weights_out, float *depth_out, sdn_stream_t stream) {
+                     const sdn_field_aux *aux, sdn_stream_t stream) {
     MlpParams p;
-    SDN_REQUIRE((weights_out == nullptr) == (depth_out == nullptr), "sdn_field_render: weights_out and depth_out go together");
-    SDN_REQUIRE(!(weights_out && term_eps > 0.f), "sdn_field_render: the per-sample outputs need term_eps = 0 (every pass must run)");
+    const bool want_aux = aux && (aux->weights || aux->depth || aux->sigma || aux->colour || aux->sky_blended || aux->nosky);
+    SDN_REQUIRE(!(want_aux && term_eps > 0.f), "sdn_field_render: the per-sample outputs need term_eps = 0 (every pass must run)");
     static const float zero3[3] = {0.f, 0.f, 0.f};
     if (cam_ori_dev && !cam_ori_host) cam_ori_host = zero3;
     if (int rc = fill_mlp(p, "sdn_field_render", packed, consts, sky_c, net_out, n_rays, num_samples, colour_terms, term_eps, passes,
@@ -2971,7 +2996,11 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
                           strat_division))
         return rc;
     p.enc.win = p.win;
-    p.cam_ori_dev = cam_ori_dev; p.w_out = weights_out; p.depth_out = depth_out;
+    p.cam_ori_dev = cam_ori_dev;
+    if (want_aux) {
+        p.w_out = aux->weights; p.depth_out = aux->depth; p.sig_out = aux->sigma; p.col_out = aux->colour;
+        p.skyb_out = aux->sky_blended; p.nosky_out = aux->nosky;
+    }
     SDN_REQUIRE(colour_terms != 2, "sdn_field_render: colour_terms must be 3 or 6 (the 2-term profile exists for sdn_field_mlp only)");
     const int wg = mlp_workgroups(p, n_workgroups);
 #ifdef SDN_MLP_ABLATION
@@ -2980,7 +3009,7 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
         if (atoi(e) == 515) { hipLaunchKernelGGL((mlp_kernel<512, 3, MODE_FUSED>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p); return sdn::check_launch("sdn_field_render"); }
     }
 #endif
-    if (weights_out) {
+    if (want_aux) {
         if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, MODE_FUSED_AUX>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
         else hipLaunchKernelGGL((mlp_kernel<0, 3, MODE_FUSED_AUX>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
     } else if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, MODE_FUSED>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);
@@ -3004,6 +3033,7 @@ int sdn_render_mlp(const float *x, const uint8_t *label, const void *packed, con
     p.win.n_src = p.R; p.win.pitch = 0; p.win.first = 0; p.win.cols = 0; p.win.ray0 = 0;
     p.sky_avg = nullptr; p.ticket = ticket;
     p.cam_ori_dev = nullptr; p.w_out = nullptr; p.depth_out = nullptr; p.sigma_out = sigma;
+    p.sig_out = nullptr; p.col_out = nullptr; p.skyb_out = nullptr; p.nosky_out = nullptr;
     p.enc = EncParams{};
     const int wg = mlp_workgroups(p, n_workgroups);
     if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, MODE_RAW>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);

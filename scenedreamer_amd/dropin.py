@@ -26,9 +26,10 @@ of a frame arrives, and serves the frame's tiles as views of that result (Genera
 the sky pre-pass / camera tensors and the version counters of the frame arrays, never through bare addresses.
 
 _forward_perpix returns the reference's 12-tuple.  `net_out` is always there.  With `aux=False` (default: the inference
-loop and Generator.forward only read `net_out`) the other eleven are None; with `aux=True` new_dists, weights,
-total_weights_raw, rand_depth, sky_mask, sky_only_mask and new_idx are produced as well (what inference_givenstyle_depth
-reads, scenedreamer.py:812-817); net_out_s, net_out_c, skynet_out_c and nosky_mask never leave the fused kernel.
+loop and Generator.forward only read `net_out`) the other eleven are None; with `binding(G, aux=True)` ALL of them are
+produced (the field kernel's MODE_FUSED_AUX instantiation writes weights, rand_depth, net_out_s, net_out_c, the blended
+skynet_out_c and nosky_mask; new_dists / new_idx come from sdn_sample_depth, the sky masks from voxel_id) -- what
+inference_givenstyle_depth reads (scenedreamer.py:812-817); tile by tile then, without the one-evaluation-per-frame shortcut.
 """
 import importlib
 import importlib.abc
@@ -299,7 +300,7 @@ def fast_forward_perpix(self, blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z
         u = None
         if not self.coarse_deterministic_sampling:            # the reference's draw, mc_utils.py:121 (nsamples = num_samples + 1)
             u = torch.rand([1, h, w, ns + 1, 1], dtype=depth2.dtype, device=depth2.device).reshape(h * w, ns + 1)
-        aux = {} if b.aux else None
+        aux = dict.fromkeys(fused.AUX_OUTPUTS) if b.aux else None
         out = [None] * len(PERPIX_OUTPUTS)
         if (b.coalesce and isinstance(sky_mean, dict) and u is None and aux is None and hasattr(self, "sky_avg") and
                 win.rows * win.cols < win.n_src):
@@ -319,6 +320,9 @@ def fast_forward_perpix(self, blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z
             rand_depth = torch.where(torch.isnan(rand_depth) | torch.isinf(rand_depth), torch.zeros_like(rand_depth), rand_depth)
             weights = aux["weights"].view(1, h, w, ns, 1)
             out[1], out[2], out[3], out[4] = new_dists, weights, weights.sum(dim=-2, keepdim=True), rand_depth
+            out[5], out[6] = aux["sigma"].view(1, h, w, ns, 1), aux["colour"].view(1, h, w, ns, 64)       # net_out_s, net_out_c
+            out[7] = aux["sky_blended"].view(1, h, w, 1, 64)                                              # skynet_out_c (blended, :401)
+            out[8] = aux["nosky"].view(1, h, w, 1, 1).to(torch.float32)                                   # nosky_mask (float, :383)
             out[9] = voxel_id[:, :, :, [-1], :] == 0
             out[10] = voxel_id[:, :, :, [0], :] == 0
             out[11] = new_idx

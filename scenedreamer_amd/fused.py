@@ -13,6 +13,9 @@ _f3 = ctypes.c_float * 3
 _i5 = ctypes.c_int32 * 5
 
 
+AUX_OUTPUTS = ("weights", "depth", "sigma", "colour", "sky_blended", "nosky")
+
+
 class Window:
     """Which rays of the frame-wide ray arrays (voxel_id [n_src,M], depth2 [2,n_src,M], raydirs [n_src,3], sky_c [n_src,64])
     a field launch evaluates: ray (y, x) of a rows x cols window is source ray first + y * pitch + x.  The kernels read
@@ -231,7 +234,9 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
     vid / d2 / rd / sky_c: tensors, or -- with a `window` -- plain device addresses (int) of frame-wide arrays of window.n_src
     rays (Generator._forward_perpix's tile views of the per-frame voxlib outputs are evaluated in place that way).
     cam_ori: host values, or a CUDA tensor -- then the kernel reads it from device memory (no device -> host copy).
-    aux: None, or a dict that receives "weights" and "depth" [n_rays, ns] (_forward_perpix's `weights` / `rand_depth`)."""
+    aux: None, or a dict: its keys (any of AUX_OUTPUTS: "weights", "depth", "sigma" [n_rays, ns], "colour" [n_rays, ns, 64],
+    "sky_blended" [n_rays, 64], "nosky" u8 [n_rays]; an empty dict = "weights" + "depth") name the other return values of
+    Generator._forward_perpix the launch should also produce; the dict receives the tensors."""
     sc = R._fused_scene or prepare_scene(R)
     st = R._fused_style or prepare_style(R)
     ct, eps = precision_profile(R)
@@ -275,11 +280,15 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
         ori = np.zeros(3, np.float32)
     else:
         ori = np.asarray(cam_ori.detach().cpu().numpy() if isinstance(cam_ori, torch.Tensor) else cam_ori, np.float32).reshape(3)
-    w_out = d_out = None
+    aux_c = None
     if aux is not None:
-        w_out = torch.zeros((n_rays, ns), dtype=torch.float32, device=R.dev)      # groups without a hit are not visited
-        d_out = torch.zeros((n_rays, ns), dtype=torch.float32, device=R.dev)
-        aux["weights"], aux["depth"] = w_out, d_out
+        shapes = {"weights": ((n_rays, ns), torch.float32), "depth": ((n_rays, ns), torch.float32), "sigma": ((n_rays, ns), torch.float32),
+                  "colour": ((n_rays, ns, 64), torch.float32), "sky_blended": ((n_rays, 64), torch.float32), "nosky": ((n_rays,), torch.uint8)}
+        want = list(aux) or ["weights", "depth"]
+        assert all(k in shapes for k in want), want
+        for k in want:
+            aux[k] = torch.empty(shapes[k][0], dtype=shapes[k][1], device=R.dev)     # (with aux the kernel visits every ray and sample)
+        aux_c = capi.FieldAux(**{k: aux[k].data_ptr() for k in want})
     with torch.cuda.device(R.dev):
         rc = _lib().sdn_field_render(p_vid, p_d2, p_rd, sc["lut"].data_ptr(), sc["table3"].data_ptr(),
                                      sc["T"], sc["scales"].data_ptr(), sc["genc"].ctypes.data, ori.ctypes.data,
@@ -289,8 +298,7 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
                                      passes.data_ptr() if passes is not None else None, 0, window.host(0),
                                      {"reciprocal": 0, "ieee": 1}[division], st["ticket"].data_ptr(),
                                      ori_dev.data_ptr() if ori_dev is not None else None,
-                                     w_out.data_ptr() if w_out is not None else None, d_out.data_ptr() if d_out is not None else None,
-                                     _stream(R.dev))
+                                     ctypes.byref(aux_c) if aux_c is not None else None, _stream(R.dev))
     capi.check(rc, "sdn_field_render")
     return net_out
 

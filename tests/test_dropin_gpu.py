@@ -151,8 +151,10 @@ def test_field_render_aux_outputs_and_device_camera(weights_full, scene256):
         sky_c, sky_avg = fused.sky_fused(R, rd)
         host = fused.field_render(R, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, ns)
         dev = fused.field_render(R, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32).cuda(), sky_c, sky_avg, ns)
-        aux = {}
+        aux = dict.fromkeys(fused.AUX_OUTPUTS)
         with_aux = fused.field_render(R, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, ns, aux=aux)
+        two = {}                 # (an empty dict asks for weights + depth only)
+        fused.field_render(R, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, ns, aux=two)
         depth, _, _ = ops.sample_depth_batched(d2.view(1, 2, H0, W0, R.M, 1), ns + 1, deterministic=True, use_box_boundaries=False,
                                                sample_depth=R.sample_depth)
         depth = depth.view(n, ns)
@@ -166,7 +168,15 @@ def test_field_render_aux_outputs_and_device_camera(weights_full, scene256):
     hit = vid[:, 0] != 0
     assert float(w[~hit].abs().max()) == 0.0 and bool((w >= 0).all()) and float(w.sum(dim=1).max()) <= 1.0 + 1e-5
     assert int(hit.sum()) > 100 and float(w[hit].sum(dim=1).max()) > 0.05
-    assert torch.equal(dp, depth)
+    assert torch.equal(dp, depth) and sorted(two) == ["depth", "weights"] and torch.equal(two["weights"], w) and torch.equal(two["depth"], dp)
+    # the volume term of net_out recomposed from the per-sample outputs: sum_k w_k (clamp(c_k) + 1) + (1 - T)(clamp(sky) + 1) - 1
+    sig, col, skyb, nosky = aux["sigma"], aux["colour"], aux["sky_blended"], aux["nosky"]
+    assert tuple(sig.shape) == (n, ns) and tuple(col.shape) == (n, ns, 64) and tuple(skyb.shape) == (n, 64) and nosky.dtype == torch.uint8
+    recomposed = (w[:, :, None] * (col.clamp(-1, 1) + 1)).sum(dim=1) + (1 - w.sum(dim=1, keepdim=True)) * (skyb.clamp(-1, 1) + 1) - 1
+    assert float((recomposed - host).abs().max()) < 1e-5
+    savg = sky_avg.reshape(1, 64)
+    assert torch.equal(skyb[nosky.bool()], savg.expand(int(nosky.sum()), 64)) and torch.equal(skyb[~nosky.bool()], sky_c[~nosky.bool()])
+    assert bool(nosky[vid[:, -1] != 0].all())
 
 
 def _generator(weights_full, scene256, fast, aux=False):
@@ -189,7 +199,7 @@ def _generator(weights_full, scene256, fast, aux=False):
 @pytest.mark.parametrize("aux", [False, True])
 def test_unmodified_generator_methods_on_the_fused_kernels(scene256, weights_full, aux):
     """Generator._forward_perpix / _forward_global of the UNMODIFIED reference with install_shims(fast=True): goldens recorded
-    from the reference itself, and -- aux -- the extra return values against the reference's own method on the same inputs."""
+    from the reference itself, and -- aux -- ALL twelve return values against the reference's own method on the same inputs."""
     import sys
     G, RH = _generator(weights_full, scene256, fast=True, aux=aux)
     from scenedreamer_amd import dropin
@@ -232,6 +242,15 @@ def test_unmodified_generator_methods_on_the_fused_kernels(scene256, weights_ful
         assert out[11].dtype == ref[11].dtype == torch.int64 and float((out[11] != ref[11]).float().mean()) < 1e-3, names[11]
         np.testing.assert_allclose(out[2].cpu().numpy(), ref[2].cpu().numpy(), rtol=0, atol=TOL, err_msg="weights")
         np.testing.assert_allclose(out[3].cpu().numpy(), ref[3].cpu().numpy(), rtol=0, atol=TOL, err_msg="total_weights_raw")
+        # net_out_s / net_out_c, per sample, rays that hit nothing included (the reference evaluates them at the camera origin).
+        # sigma is the quantity the density head amplifies (a 1e-4 feature change moves it by ~1e-2): judged relative to its size
+        assert all(o is not None for o in out) and [tuple(o.shape) for o in out] == [tuple(r.shape) for r in ref]
+        for i, q99, worst in ((5, 5e-3, 0.25), (6, 2e-3, 0.05)):
+            e = ((out[i] - ref[i]).abs() / (1 + ref[i].abs())).flatten()
+            k = max(1, int(0.99 * e.numel()))
+            assert float(e.kthvalue(k).values) < q99 and float(e.max()) < worst, (names[i], float(e.kthvalue(k).values), float(e.max()))
+        np.testing.assert_allclose(out[7].cpu().numpy(), ref[7].cpu().numpy(), rtol=0, atol=TOL, err_msg="skynet_out_c")
+        assert out[8].dtype == ref[8].dtype and float((out[8] != ref[8]).float().mean()) < 1e-3, "nosky_mask"
         print(f"golden {tag}: weights max abs diff vs the reference's own method {float((out[2] - ref[2]).abs().max()):.2e}")
 
 

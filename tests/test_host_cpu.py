@@ -118,7 +118,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/sdnative.h but not exported"
     assert set(capi.declared_symbols()) <= set(declared)
-    assert lib.sdn_abi_version() == 2
+    assert lib.sdn_abi_version() == 3
 
 
 def _header_prototypes():
