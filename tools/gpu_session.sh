@@ -9,6 +9,7 @@
 #   bench      bench.py headline (20 steps) without the CPU leg
 #   benchfull  bench.py exactly as the driver runs it (defaults)
 #   dropin     bench.py --only dropin
+#   light      tools/prof_light.sh: test subset + kernel trace + PMC passes + the driver's bench command (evidence refresh)
 #   prof       tools/prof_final.sh: full suite + driver bench + rocprofv3 kernel trace + PMC passes, summaries -> gpurun_out/<label>_*
 #   any other word: executed as tools/<word>.sh if it exists
 set -u
@@ -27,6 +28,7 @@ for step in "$@"; do
     bench) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${label}_bench.json 2> gpurun_out/${label}_bench.err; echo "rc=$?"; tail -c 1500 gpurun_out/${label}_bench.json; tail -5 gpurun_out/${label}_bench.err ;;
     benchfull) timeout 900 python bench.py > gpurun_out/${label}_benchfull.json 2> gpurun_out/${label}_benchfull.err; echo "rc=$?"; tail -c 3000 gpurun_out/${label}_benchfull.json; tail -5 gpurun_out/${label}_benchfull.err ;;
     dropin) timeout 900 python bench.py --only dropin > gpurun_out/${label}_dropin.json 2> gpurun_out/${label}_dropin.err; echo "rc=$?"; tail -c 3000 gpurun_out/${label}_dropin.json; tail -8 gpurun_out/${label}_dropin.err ;;
+    light) bash tools/prof_light.sh "$(cat tools/.commit 2>/dev/null)" $label ;;
     prof)  bash tools/prof_final.sh "$(cat tools/.commit 2>/dev/null)" $label ;;
     *)     if [ -x tools/$step.sh ]; then tools/$step.sh $label; else echo "unknown step $step"; fi ;;
   esac
