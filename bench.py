@@ -763,7 +763,7 @@ def main():
         }
         gates = {"cnn": getattr(R, "cnn_calibration", None),
                  "field": {k: v for k, v in (getattr(R, "field_gate", None) or {}).items() if k != "measurements"} or None,
-                 "colour_terms": (getattr(R, "field_gate", None) or {}).get("colour")}
+                 "colour_terms": (getattr(R, "field_gate", None) or {}).get("colour"), "sky": (getattr(R, "field_gate", None) or {}).get("sky")}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, weights, scene, R.z.cpu().numpy(), R.global_enc.cpu().numpy())
             # a reduced-precision internal path is named (`dtype`) together with its MEASURED max-abs error:

@@ -389,6 +389,16 @@ def prepare_sky(R):
     return R._fused_sky
 
 
+def sky_terms(R):
+    """Products of the sky MLP's hidden layers fc2..fc5: 3 = 3-term f16 split; 6 = f16 Whi.Xhi + block-scaled fp6 corrections (the
+    colour layers' scheme: ~15 % less sky time, errors of the four layers stack to ~1e-4 on sky_c).  Renderer.sky_terms, else
+    SDN_SKY_TERMS, else the per-style decision of Renderer.calibrate_style (`sky_terms_auto`), else 3."""
+    t = getattr(R, "sky_terms", None)
+    if t is None and "SDN_SKY_TERMS" in os.environ:
+        t = int(os.environ["SDN_SKY_TERMS"])
+    return t or getattr(R, "sky_terms_auto", None) or 3
+
+
 def sky_fused(R, rd, encoded=False):
     """sky_c [R,64] and the frame mean sky_avg [1,64] for ray directions rd [R,3] (the mean is finished inside the kernel by
     its last workgroup: fixed summation order, no host-side reduction).
@@ -404,7 +414,7 @@ def sky_fused(R, rd, encoded=False):
         sk["counter"] = torch.zeros(1, dtype=torch.int32, device=R.dev)     # the kernel leaves it at zero
     # hidden layers fc2..fc5: 3 = 3-term f16 split (default); 6 = f16 + fp6 corrections: 1.02 -> 0.87 ms per frame, but all
     # four hidden layers stack their ~2^-17 errors (1.1e-4 max on sky_c against 4.5e-6): opt-in
-    terms = 3 if encoded else (getattr(R, "sky_terms", None) or int(os.environ.get("SDN_SKY_TERMS", "3")))
+    terms = 3 if encoded else sky_terms(R)
     with torch.cuda.device(R.dev):
         capi.check(_lib().sdn_sky_mlp(rd.data_ptr(), sk["packed_mx" if terms == 6 else "packed"].data_ptr(), sk["consts"].data_ptr(),
                                       sky_c.data_ptr(), part.data_ptr(), n, 0, sky_avg.data_ptr(), sk["counter"].data_ptr(),

@@ -138,6 +138,7 @@ class Renderer:
         self._fused_scene = None
         self.field_gate = None           # (the collapsed table changes with global_enc)
         self.colour_terms_auto = None
+        self.sky_terms_auto = None
 
     def set_style(self, style):
         w = self.w
@@ -158,6 +159,7 @@ class Renderer:
             fold_denoiser(self, z)
         self.field_gate = None           # the per-style precision gates of the field (calibrate_field) are re-evaluated
         self.colour_terms_auto = None
+        self.sky_terms_auto = None
 
     # ------------------------------------------------------------------ stages
     def cast_rays(self, pose, resolution_hw):
@@ -277,6 +279,7 @@ class Renderer:
         self.cnn_calibration = None
         self.field_gate = None
         self.colour_terms_auto = None
+        self.sky_terms_auto = None
 
     # ------------------------------------------------------------------ per-style precision gates
     def calibrate_style(self, pose, resolution_hw, num_samples):
@@ -318,8 +321,20 @@ class Renderer:
                                                    sky32[r:r + CAL_CHUNK], savg32, num_samples, placement="kernel")
                                 for r in range(0, n, CAL_CHUNK)], dim=0)
             ref_img = inner(self.render_cnn(ref_no.view(1, H0, W0, 64)))
-            # ---- the fused field
+            # ---- the sky MLP: hidden layers as f16 + fp6 corrections if its features stay within SKY_AUTO_BOUND of the fp32 ones
+            explicit_sky = getattr(self, "sky_terms", None) or (int(os.environ["SDN_SKY_TERMS"]) if "SDN_SKY_TERMS" in os.environ else None)
+            self.sky_terms_auto = None
             sky_c, sky_avg = fused.sky_fused(self, rd)
+            sky_err = {fused.sky_terms(self): float((sky_c - sky32).abs().max())}
+            if explicit_sky is None:
+                self.sky_terms_auto = 6
+                c6, a6 = fused.sky_fused(self, rd)
+                sky_err[6] = float((c6 - sky32).abs().max())
+                if sky_err[6] <= SKY_AUTO_BOUND:
+                    sky_c, sky_avg = c6, a6
+                else:
+                    self.sky_terms_auto = None
+            # ---- the fused field
             explicit_ct = getattr(self, "colour_terms", None)
             if explicit_ct is None and "SDN_MLP_COLOUR_TERMS" in os.environ:
                 explicit_ct = int(os.environ["SDN_MLP_COLOUR_TERMS"])
@@ -331,7 +346,7 @@ class Renderer:
                     no[ct] = fused.field_fused(self, vid, d2, rd, ori, sky_c, sky_avg, num_samples)
             finally:
                 self.colour_terms = saved
-            meas = {"field_err": {ct: float((v - ref_no).abs().max()) for ct, v in no.items()}}
+            meas = {"field_err": {ct: float((v - ref_no).abs().max()) for ct, v in no.items()}, "sky_err": sky_err, "explicit_sky": explicit_sky}
             if explicit_ct is None:
                 meas["colour_diff"] = float((no[6] - no[3]).abs().max())
             ct = explicit_ct if explicit_ct is not None else (6 if meas["colour_diff"] <= COLOUR_AUTO_BOUND else 3)
@@ -373,8 +388,12 @@ class Renderer:
             "colour": ({"terms": ct, "set_explicitly": True} if ect is not None else
                        {"terms": ct, "max_abs_diff_fp6_vs_3term": meas["colour_diff"], "bound": COLOUR_AUTO_BOUND}),
             "image_err_vs_fp32": ierr[et if et is not None else cal["terms3x3"]], "image_bound": IMAGE_AUTO_BOUND,
+            "sky": {"hidden_terms": (meas.get("explicit_sky") or (6 if meas.get("sky_err", {}).get(6, 1.0) <= SKY_AUTO_BOUND else 3)),
+                    "max_abs_err_vs_fp32": meas.get("sky_err"), "bound": SKY_AUTO_BOUND, "set_explicitly": meas.get("explicit_sky") is not None},
             "rays": meas["rays"], "samples_per_ray": meas["samples_per_ray"], "frame": meas["frame"], "measurements": meas}
         self.colour_terms_auto = ct if ect is None else None
+        if "sky_err" in meas:
+            self.sky_terms_auto = 6 if (meas.get("explicit_sky") is None and meas["sky_err"].get(6, 1.0) <= SKY_AUTO_BOUND) else None
         if cal is not None:
             self.cnn_calibration = cal
             cache = self.__dict__.setdefault("_mfma_cnns", {})
@@ -453,6 +472,7 @@ class Renderer:
         eps = fused.precision_profile(self)[1]
         return (f"f32 (hash grid) + f16 MFMA with f32 accumulate{f' (early ray termination at transmittance {eps:g})' if eps > 0 else ''}: field/sky MLP 3-term split"
                 f"{' (colour layers 2-term)' if ct == 2 else ' (colour layers: f16 Whi.Xhi + MX-fp6 corrections)' if ct == 6 else ''}"
+                f"{' (sky hidden layers: f16 + MX-fp6 corrections)' if fused.sky_terms(self) == 6 else ''}"
                 f", render CNN 1x1 3-term / 3x3 {t3}")
 
     def measure_roofline(self, pose, resolution_hw, num_samples, mode, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0):
@@ -935,6 +955,7 @@ FIELD_AUTO_BOUND = 1e-3    # largest net_out error of the fused field vs the fp3
                            # pose (rms 2e-5; ~80 values above 5e-4): the density head sums ~2e3 x its result in cancelling terms, so the
                            # 22-bit operands of the 3-term split put ~1e-3 on sigma where fp32 itself (vs fp64) is off by 1.4e-4
 IMAGE_AUTO_BOUND = 8e-4    # largest image error of the whole fused path vs the fp32 path, whole frame
+SKY_AUTO_BOUND = 2e-4      # largest sky_c error (vs PyTorch fp32) at which the sky MLP's hidden layers run as f16 + fp6 corrections
 CAL_MAX_PIXELS = 1 << 20   # frames above this many pixels are calibrated at a reduced resolution (same pose)
 CAL_CHUNK = 1 << 16        # rays per launch group of the fp32 field
 MISS_COST = 0.2            # row_costs: cost of a ray that hits nothing relative to one that does (ray casting + sky MLP + CNN vs + field)
