@@ -736,22 +736,21 @@ class Renderer:
             if mode != "fused":
                 cam_ori = cam_ori.to(self.dev)
             if mode == "fused":
+                # per-style precision gates (once per style; a host synchronisation on the style's first frame) -- before the sky
+                # MLP of this frame, whose hidden-layer form is one of the decisions
+                if getattr(self, "field_gate", None) is None and FIELD_GATE:
+                    self.calibrate_style(pose, resolution_hw, num_samples)
+                if self.field_falls_back():      # this style / these weights are outside the fused path's tolerance: the fp32 op
+                    mode, cam_ori = "unfused", cam_ori.to(self.dev)       # sequence, all of it (sky MLP and CNN included)
+                    if cnn_mode is None:
+                        cnn_mode = "torch"
+            if mode == "fused":
                 from . import fused
                 sky_c, sky_avg = fused.sky_fused(self, rd)
             else:
                 sky_c = self.sky_features(rd)
                 sky_avg = sky_c.mean(dim=0, keepdim=True)    # full-frame mean, scenedreamer.py:592-598
             ev.mark("sky")
-            if mode == "fused":
-                # per-style precision gates of the field (once per style; a host synchronisation on the style's first frame)
-                if getattr(self, "field_gate", None) is None and FIELD_GATE:
-                    self.calibrate_style(pose, resolution_hw, num_samples)
-                if self.field_falls_back():      # this style / these weights are outside the fused path's tolerance: the fp32 op
-                    mode, cam_ori = "unfused", cam_ori.to(self.dev)       # sequence, all of it (sky MLP and CNN included)
-                    sky_c = self.sky_features(rd)
-                    sky_avg = sky_c.mean(dim=0, keepdim=True)
-                    if cnn_mode is None:
-                        cnn_mode = "torch"
             crop = self.pad // 2
             window = None
             if mode == "fused" and cnn and apron == "minimal" and crop > CNN_HALO:
