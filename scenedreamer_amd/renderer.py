@@ -415,14 +415,18 @@ class Renderer:
     def mfma_cnn(self, net_out):
         """The MFMA render CNN (cnn.MfmaCNN) for the current precision profile.
 
-        The four 3x3 convolutions can run as ONE f16 product (operands rounded to nearest: a third of the MFMAs, 3.4 ms
-        instead of 7.3 ms per 960x540 frame) or as the 3-term f16 split (agrees with the fp32 CNN to < 2e-5).  The
-        1-term form is LOSSY -- its error grows with the activations' magnitude, i.e. it depends on the loaded weights
-        and the style -- so it is not a blind default: with cnn_terms3x3 = None ("auto") the first net_out presented
-        after a style change is pushed through both forms, and the 1-term kernels are used only if their image differs
-        from the 3-term image by at most CNN_AUTO_BOUND (max abs) on that frame; otherwise the 3-term kernels are.
-        The decision and the measured difference are kept in `cnn_calibration` (bench.py prints them).  An explicit
-        cnn_terms3x3 (set_precision, or SDN_CNN_TERMS in the environment) bypasses the gate."""
+        The four 3x3 convolutions can run as ONE f16 product (operands rounded to nearest: a third of the MFMAs, 2.9 ms
+        instead of 7.3 ms per 960x540 frame) or as the 3-term f16 split (agrees with the fp32 CNN to < 2e-5).  The 1-term form
+        is LOSSY -- its error grows with the activations' magnitude, i.e. it depends on the loaded weights and the style -- so
+        it is not a blind default.  Who decides (cnn_terms3x3 = None, "auto"):
+          * Renderer.calibrate_style, end to end, on the style's first frame (the record `cnn_calibration` then says
+            `measured: end to end`): 1-term only if its image is within CNN_AUTO_BOUND of the 3-term image AND within
+            IMAGE_AUTO_BOUND of the fp32 image;
+          * where no fp32 twin is at hand (modules.Backend: the drop-in binding; bands rendered without dist.agree_precision), the
+            window below: every net_out presented until CNN_CAL_PIXELS pixels of the style have been seen goes through both
+            forms; the 1-term image is used while every comparison stayed within CNN_AUTO_BOUND and the charged field error plus
+            that difference within IMAGE_BUDGET; the first violation closes the gate for the style.
+        An explicit cnn_terms3x3 (set_precision, or SDN_CNN_TERMS in the environment) bypasses the gate."""
         cache = self.__dict__.setdefault("_mfma_cnns", {})
         get = self._cnn_form
 
