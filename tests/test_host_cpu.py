@@ -362,3 +362,38 @@ def test_bench_cpu_baseline_reference_leg_equals_the_oracle(scene256, weights_fu
     for k in picks:
         assert got[k][:2] == ref[k][:2]
         assert torch.equal(got[k][2], ref[k][2])
+
+
+def test_precision_decisions_follow_the_measurements():
+    """Renderer.adopt_precision is a pure function of calibrate_style's measurements (dist.agree_precision re-runs it on the
+    MAX over ranks): every gate opens and closes at its bound, explicit settings are recorded but not overridden."""
+    from scenedreamer_amd import renderer as rmod
+    R = object.__new__(rmod.Renderer)
+
+    def meas(**kw):
+        m = dict(field_err={6: 6e-4, 3: 6e-4}, colour_diff=5e-5, image_err={1: 4e-4, 3: 2e-4}, cnn_diff=4e-4, sky_err={3: 4e-6, 6: 1e-4},
+                 explicit_colour=None, explicit_cnn=None, explicit_sky=None, pixels=518400, rays=564300, samples_per_ray=24, frame="t")
+        m.update(kw)
+        return m
+    g = R.adopt_precision(meas())
+    assert g["path"] == "fused" and g["colour"]["terms"] == 6 and R.colour_terms_auto == 6 and R.sky_terms_auto == 6
+    assert R.cnn_calibration["terms3x3"] == 1 and g["sky"]["hidden_terms"] == 6 and g["image_err_vs_fp32"] == 4e-4
+    g = R.adopt_precision(meas(colour_diff=2e-4, sky_err={3: 4e-6, 6: 3e-4}))
+    assert g["colour"]["terms"] == 3 and R.colour_terms_auto == 3 and R.sky_terms_auto is None and g["sky"]["hidden_terms"] == 3
+    g = R.adopt_precision(meas(cnn_diff=6e-4))                                   # 1-term too far from 3-term
+    assert R.cnn_calibration["terms3x3"] == 3 and g["path"] == "fused" and g["image_err_vs_fp32"] == 2e-4
+    g = R.adopt_precision(meas(image_err={1: 9e-4, 3: 2e-4}))                    # 1-term outside the image budget
+    assert R.cnn_calibration["terms3x3"] == 3 and g["path"] == "fused"
+    g = R.adopt_precision(meas(image_err={1: 3e-3, 3: 1.2e-3}, cnn_diff=2e-3))   # even the 3-term image is out: fp32 path
+    assert g["path"] == "unfused" and R.field_falls_back()
+    g = R.adopt_precision(meas(field_err={6: 1.2e-3, 3: 1.2e-3}))                # the field itself is out
+    assert g["path"] == "unfused"
+    g = R.adopt_precision(meas(field_err={6: 9.9e-4, 3: 9.9e-4}))                # ... the bound is the radiance tolerance
+    assert g["path"] == "fused" and g["bound"] == rmod.FIELD_AUTO_BOUND == 1e-3
+    R.cnn_calibration = None
+    g = R.adopt_precision(meas(explicit_colour=3, explicit_cnn=1, explicit_sky=3, field_err={3: 5e-4}, image_err={1: 4e-4}))
+    assert g["colour"] == {"terms": 3, "set_explicitly": True} and R.colour_terms_auto is None and R.cnn_calibration is None
+    assert g["sky"]["set_explicitly"] and R.sky_terms_auto is None
+    R.cnn_auto_bound = 1e-7
+    R.adopt_precision(meas())
+    assert R.cnn_calibration["terms3x3"] == 3 and R.cnn_calibration["bound"] == 1e-7
