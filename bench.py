@@ -61,7 +61,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", default=os.environ.get("SDN_BENCH_MODE", "auto"), choices=["auto", "fused", "unfused"])
+    ap.add_argument("--mode", default=os.environ.get("SDN_BENCH_MODE", "auto"), choices=["auto", "fused", "unfused", "dropin"],
+                    help="fused / unfused: which per-pixel path this package's frame loop uses; dropin = --only dropin (the UNMODIFIED "
+                         "reference generator's inference_givenstyle loop on install_shims(fast=True))")
     ap.add_argument("--height", type=int, default=540)
     ap.add_argument("--width", type=int, default=960)
     ap.add_argument("--samples", type=int, default=24)
@@ -102,6 +104,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the `other_configs` record")
     ap.add_argument("--dropin-frames", type=int, default=12, help="frames of the reference's loop per tile size in the `dropin` record")
     args = ap.parse_args()
+    if args.mode == "dropin":
+        args.mode, args.only = "auto", "dropin"
     if args.profile:
         args.no_extras = args.no_cpu_baseline = args.no_dropin = args.no_other_configs = True
         os.environ.setdefault("SDN_FIELD_GATE", "0")    # no calibration launches in the trace (scenedreamer_amd.renderer.FIELD_GATE)
