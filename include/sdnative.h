@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SDN_ABI_VERSION 3
+#define SDN_ABI_VERSION 4
 
 typedef void *sdn_stream_t; /* hipStream_t */
 
@@ -176,7 +176,12 @@ size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples);
 int sdn_field_collapse_table(const float *embeddings, const int32_t *offsets_host, uint32_t L, float S, uint32_t H,
                              const float *genc_host, float *table3, sdn_stream_t stream);
 /* w1 dev [256,128] fc_1.weight; wh5_host: host array of 5 dev pointers [256,256] = fc_2..fc_6 weight * alpha;
- * wc dev [64,256] fc_out_c.weight; packed dev, sdn_field_packed_weight_bytes() bytes */
+ * wc dev [64,256] fc_out_c.weight; packed dev, sdn_field_packed_weight_bytes() bytes.
+ * The trunk layers fc_1 .. fc_4 are stored times 2^sdn_field_trunk_shift() (the MLP kernels take the factor back out), so
+ * that the lo halves of the f16 split leave f16's subnormal range: the caller must keep
+ * max(|fc_1.weight|, 0.4 |fc_2..4 weight * alpha|) * 2^sdn_field_trunk_shift() below f16's 65504 (not checked here: the
+ * weights are device memory; the host wrapper fused.prepare_style checks it). */
+int sdn_field_trunk_shift(void);
 int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const float *wc, void *packed,
                            sdn_stream_t stream);
 /* The same stream (same size) with the colour layers fc_5 / fc_6 laid out for colour_terms = 6 of sdn_field_mlp: f16 Whi

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "sdn_field_feat_bytes": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "sdn_field_aux_elems": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "sdn_field_collapse_table": (c_i, [c_p, c_p, c_u, c_f, c_u, c_p, c_p, c_p]),
+    "sdn_field_trunk_shift": (c_i, []),
     "sdn_field_pack_weights": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_field_pack_weights_mx": (c_i, [c_p, c_p, c_p, c_p, c_p]),
     "sdn_field_encode": (c_i, [c_p, c_p, c_p, c_p, c_p, c_u, c_p, c_p, c_p, c_p, c_p, c_p, ctypes.c_int32, ctypes.c_int32,
@@ -113,7 +114,7 @@ def lib():
                     fn = getattr(L, name)  # AttributeError if the symbol is not exported
                     fn.restype = res
                     fn.argtypes = args
-                if L.sdn_abi_version() != 3:
+                if L.sdn_abi_version() != 4:
                     raise ImportError("libsdnative ABI version mismatch")
                 _lib = L
     return _lib

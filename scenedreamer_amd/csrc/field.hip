@@ -71,6 +71,13 @@ constexpr int SAMP_PER_STEP = 4;
 constexpr int MAXM = 8;
 constexpr int MAX_LIN = 80;     // up to 78 samples per ray
 constexpr float ACT_SCALE = 0.4f; // LeakyReLU_0.2(x) = 0.4 * (1.5 x + |x|)
+// The packed weights of the trunk layers fc_1 .. fc_4 carry 2^TRUNK_SHIFT (pack_kernel has the reason); the MLP kernel takes
+// the factor back out of their accumulators in the activation's bias fma.  -DSDN_TRUNK_SHIFT=0 is the ablation build.
+#ifndef SDN_TRUNK_SHIFT
+#define SDN_TRUNK_SHIFT 8
+#endif
+constexpr int TRUNK_SHIFT = SDN_TRUNK_SHIFT;
+constexpr float TRUNK_K = 1.0f / (float)(1 << TRUNK_SHIFT);
 
 // ---- packed weight layout (in units of half8 = one lane's fragment) ---------------------------------
 // layer 0: fc_1   K=128 -> 8 k-steps, 8 row blocks
@@ -277,7 +284,11 @@ __global__ __launch_bounds__(256) void pack_kernel(const PackParams p) {
         const int k = layer == 0 ? kmap_first(s, h, e) : kmap_hidden(s, h, e);
         // layers 1..6 consume a' = 1.5 x + |x| = LeakyReLU_0.2(x) / 0.4 (one v_fma instead of mul + max in the
         // MLP kernel's activation), so their weights carry the factor 0.4
-        const float v = W[(size_t)row * K + k] * (layer == 0 ? 1.0f : ACT_SCALE);
+        // The trunk layers (fc_1 .. fc_4, whose error the density head amplifies) are stored times 2^TRUNK_SHIFT: the lo
+        // part of a weight of magnitude 0.03 is ~7e-6, deep in f16's subnormal range (quantum 6e-8), which left the split
+        // weight with ~20 significant bits instead of 22; scaled by 2^shift the quantum shrinks by as much.  The kernel
+        // takes the factor back out in the bias fma of the activation (act_stage, stage 1) -- no extra instruction.
+        const float v = W[(size_t)row * K + k] * (layer == 0 ? 1.0f : ACT_SCALE) * (layer <= 3 ? (float)(1 << TRUNK_SHIFT) : 1.0f);
         const _Float16 vh = (_Float16)v;
         hi[e] = vh;
         lo[e] = (_Float16)(v - (float)vh);
@@ -998,14 +1009,14 @@ __device__ __forceinline__ void act_fetch(const float *bias, const float *wsig, 
 // LO = false: the consumer of this fragment is a 2-term layer (no Whi.Xlo product): only hi is produced
 template <int T, int HS, bool SIG, int STAGE, bool LO = true>
 __device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const ActIn &in, half8 (&bh)[16], half8 (&bl)[16],
-                                          float &part, ActRegs &g) {
+                                          float &part, ActRegs &g, float k = 1.f) {
     constexpr int IB = T / 2, Q = T % 2;
     if constexpr (STAGE == 0) {
 #pragma unroll
         for (int e = 0; e < 4; e++) g.y[e] = acc[IB][8 * Q + 4 * HS + e];                 // 4 x v_accvgpr_read
     } else if constexpr (STAGE == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) g.y[e] += in.b[e];
+        for (int e = 0; e < 4; e++) g.y[e] = __builtin_fmaf(g.y[e], k, in.b[e]);   // k == 1 (a literal): folds to v_add
     } else if constexpr (STAGE == 2) {
         // a' = 1.5 x + |x| = LeakyReLU_0.2(x) / 0.4 : ONE v_fma (|x| is a free source modifier); the 0.4 lives in
         // the next layer's packed weights and in the density-head weights
@@ -1036,14 +1047,14 @@ __device__ __forceinline__ void act_stage(const f32x16 (&acc)[8], const ActIn &i
 // whole half-fragment at once (used where nothing can hide it: the tail of the first layer)
 template <int T, int HS, bool SIG>
 __device__ __forceinline__ void act_half(const f32x16 (&acc)[8], const float *bias, const float *wsig, int h, half8 (&bh)[16],
-                                         half8 (&bl)[16], float &part) {
+                                         half8 (&bl)[16], float &part, float k = 1.f) {
     ActRegs g;
     ActIn in;
     act_fetch<T, HS, SIG>(bias, wsig, h, in);
     if constexpr (SIG) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in.b), "+v"(in.w)::"memory");
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in.b)::"memory");
     act_stage<T, HS, SIG, 0>(acc, in, bh, bl, part, g);
-    act_stage<T, HS, SIG, 1>(acc, in, bh, bl, part, g);
+    act_stage<T, HS, SIG, 1>(acc, in, bh, bl, part, g, k);
     act_stage<T, HS, SIG, 2>(acc, in, bh, bl, part, g);
     act_stage<T, HS, SIG, 3>(acc, in, bh, bl, part, g);
     act_stage<T, HS, SIG, 4>(acc, in, bh, bl, part, g);
@@ -1052,9 +1063,9 @@ __device__ __forceinline__ void act_half(const f32x16 (&acc)[8], const float *bi
 
 template <int T, bool SIG>
 __device__ __forceinline__ void act_step(const f32x16 (&acc)[8], const float *bias, const float *wsig, int h, half8 (&bh)[16],
-                                         half8 (&bl)[16], float &part) {
-    act_half<T, 0, SIG>(acc, bias, wsig, h, bh, bl, part);
-    act_half<T, 1, SIG>(acc, bias, wsig, h, bh, bl, part);
+                                         half8 (&bl)[16], float &part, float k = 1.f) {
+    act_half<T, 0, SIG>(acc, bias, wsig, h, bh, bl, part, k);
+    act_half<T, 1, SIG>(acc, bias, wsig, h, bh, bl, part, k);
 }
 
 // One 8-row-block layer (NS k-steps) from the LDS ring.
@@ -1175,7 +1186,7 @@ constexpr bool layer8_spread(int NS, bool HAS_PEND, int TERMS) { return NS == 16
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS, bool LO_PEND, bool LO_OWN, int U>
 __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16],
                                             f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
-                                            int h, float &part) {
+                                            int h, float &part, float k_own, float k_pend) {
     constexpr int UNITS = NS * 4, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
     constexpr bool SPREAD = layer8_spread(NS, HAS_PEND, TERMS) && !(DBG & 16);
     using P = ActPlan<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U, SPREAD>;
@@ -1202,7 +1213,7 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
     layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, U + 1, SPREAD>(bias, bias_pend, wsig, h, st);
 #define SDN_STAGE(K) \
     if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
-    if constexpr (P::stage(K) >= 0) act_stage<T, HS, SIG, P::stage(K) < 0 ? 0 : P::stage(K), LO>(acc, in, bh, bl, part, g); \
+    if constexpr (P::stage(K) >= 0) act_stage<T, HS, SIG, P::stage(K) < 0 ? 0 : P::stage(K), LO>(acc, in, bh, bl, part, g, P::PEND ? k_pend : k_own); \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (DBG & 16) {
@@ -1243,13 +1254,16 @@ __device__ __forceinline__ void layer8_unit(char *lds, Ring &r, LayerState &st, 
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS, bool LO_PEND, bool LO_OWN, int... Us>
 __device__ __forceinline__ void layer8_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st,
                                              half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8], const float *bias,
-                                             const float *bias_pend, const float *wsig, int h, float &part) {
-    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN, Us>(lds, r, st, bh, bl, acc, bias, bias_pend, wsig, h, part), ...);
+                                             const float *bias_pend, const float *wsig, int h, float &part, float k_own,
+                                             float k_pend) {
+    (layer8_unit<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN, Us>(lds, r, st, bh, bl, acc, bias, bias_pend, wsig, h, part,
+                                                                                   k_own, k_pend), ...);
 }
 
 template <int DBG, int NS, bool HAS_PEND, bool SIG_PEND, bool SIG_OWN, int TERMS = 3, bool LO_PEND = true, bool LO_OWN = true>
 __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], f32x16 (&acc)[8],
-                                       const float *bias, const float *bias_pend, const float *wsig, int h, float &part) {
+                                       const float *bias, const float *bias_pend, const float *wsig, int h, float &part,
+                                       float k_own = 1.f, float k_pend = 1.f) {
     LayerState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
@@ -1257,7 +1271,7 @@ __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
     layer8_units<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, TERMS, LO_PEND, LO_OWN>(std::make_integer_sequence<int, NS * 4>{}, lds, r, st, bh,
-                                                                             bl, acc, bias, bias_pend, wsig, h, part);
+                                                                             bl, acc, bias, bias_pend, wsig, h, part, k_own, k_pend);
 }
 
 // =====================================================================================================
@@ -1346,8 +1360,8 @@ __device__ __forceinline__ void mx_block_max_f16(const half8 (&bh)[16], MxState 
 // act_stage + running block max (the f32 activations of stage 2 are at hand in stage 3)
 template <int T, int HS, bool SIG, int STAGE, bool MXT>
 __device__ __forceinline__ void act_stage_x(const f32x16 (&acc)[8], const ActIn &in, half8 (&bh)[16], half8 (&bl)[16], MxState &mx,
-                                            float &part, ActRegs &g) {
-    act_stage<T, HS, SIG, STAGE, true>(acc, in, bh, bl, part, g);
+                                            float &part, ActRegs &g, float k = 1.f) {
+    act_stage<T, HS, SIG, STAGE, true>(acc, in, bh, bl, part, g, k);
     if constexpr (MXT && STAGE == 3) {
         float m = mx.bm[T / 4];
         asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(m) : "v"(m), "v"(g.x[0]), "v"(g.x[1]));
@@ -1367,7 +1381,7 @@ __device__ __forceinline__ void act_stage_x(const f32x16 (&acc)[8], const ActIn 
 template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN, int U>
 __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st, half8 (&bh)[16], half8 (&bl)[16], MxState &mx,
                                              f32x16 (&acc)[8], const float *bias, const float *bias_pend, const float *wsig,
-                                             int h, float &part) {
+                                             int h, float &part, float k_own, float k_pend) {
     constexpr int NS = 16, UNITS = 64, RD = RING_DEPTH, UPS = UNITS_PER_SLOT;
     constexpr bool MXL = KIND != 0;
     constexpr bool SPREAD = !MXL;   // MX units (4 or 2 MFMAs) are issue-bound wherever the activation work goes
@@ -1396,7 +1410,7 @@ __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st,
 #define SDN_STAGE(K) \
     if constexpr (U % UPS < PIECES / 4 && K < 4 && !(DBG & 1)) ring_issue_piece<4 * (U % UPS) + ((K) & 3)>(lds, r); \
     if constexpr (CONV >= 0 && K == 0) mx_convert<CONV < 0 ? 0 : CONV>(bh, bl, mx); \
-    if constexpr (P::stage(K) >= 0) act_stage_x<T, HS, SIG, P::stage(K) < 0 ? 0 : P::stage(K), MXT>(acc, in, bh, bl, mx, part, g); \
+    if constexpr (P::stage(K) >= 0) act_stage_x<T, HS, SIG, P::stage(K) < 0 ? 0 : P::stage(K), MXT>(acc, in, bh, bl, mx, part, g, P::PEND ? k_pend : k_own); \
     if constexpr (PF && K < 4) lds_frag<UN % UPS, (K) & 3>(r, pf_pos, nx[(K) & 3]); \
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!MXL) {
@@ -1449,13 +1463,15 @@ __device__ __forceinline__ void layer8x_unit(char *lds, Ring &r, LayerState &st,
 template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN, int... Us>
 __device__ __forceinline__ void layer8x_units(std::integer_sequence<int, Us...>, char *lds, Ring &r, LayerState &st, half8 (&bh)[16],
                                               half8 (&bl)[16], MxState &mx, f32x16 (&acc)[8], const float *bias,
-                                              const float *bias_pend, const float *wsig, int h, float &part) {
-    (layer8x_unit<DBG, KIND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, mx, acc, bias, bias_pend, wsig, h, part), ...);
+                                              const float *bias_pend, const float *wsig, int h, float &part, float k_own,
+                                              float k_pend) {
+    (layer8x_unit<DBG, KIND, SIG_PEND, SIG_OWN, Us>(lds, r, st, bh, bl, mx, acc, bias, bias_pend, wsig, h, part, k_own, k_pend), ...);
 }
 
 template <int DBG, int KIND, bool SIG_PEND, bool SIG_OWN>
 __device__ __forceinline__ void layer8x(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], MxState &mx, f32x16 (&acc)[8],
-                                        const float *bias, const float *bias_pend, const float *wsig, int h, float &part) {
+                                        const float *bias, const float *bias_pend, const float *wsig, int h, float &part,
+                                        float k_own = 1.f, float k_pend = 1.f) {
     LayerState st;
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
@@ -1463,7 +1479,7 @@ __device__ __forceinline__ void layer8x(char *lds, Ring &r, half8 (&bh)[16], hal
     lds_unit<0>(r, st.pos_cur, st.ring[0]);
     lds_unit<1>(r, st.pos_cur, st.ring[1]);
     layer8x_units<DBG, KIND, SIG_PEND, SIG_OWN>(std::make_integer_sequence<int, 64>{}, lds, r, st, bh, bl, mx, acc, bias, bias_pend,
-                                                wsig, h, part);
+                                                wsig, h, part, k_own, k_pend);
 }
 
 // Output layer (2 row blocks, 16 k-steps, one unit per k-step); the lower half of the last hidden layer is
@@ -1824,8 +1840,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             // ---- fc_1: 8 k-steps; fragments 0..6 of its upper half are activated behind its own lower half, fragment 7
             //      right after it, its lower half behind fc_2's head ---------------------------------------------------
             const float *bias1 = cst + C_LABEL_BIAS + lab * HID;
-            layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, bias1, bias1, wsig, h, part);
-            act_step<7, false>(acc, bias1, wsig, h, bh, bl, part);   // fragments 0..6 were activated inside the layer
+            layer8<DBG, 8, false, false, false>(lds, r, bh, bl, acc, bias1, bias1, wsig, h, part, TRUNK_K, TRUNK_K);
+            act_step<7, false>(acc, bias1, wsig, h, bh, bl, part, TRUNK_K);   // fragments 0..6 were activated inside the layer
             seg_tick<DBG>(lds, 1, t_seg);
             // ---- fc_2 .. fc_6.  fc_4 (l == 2) feeds the density head (layers.py:114): its upper half is activated
             //      inside l == 2, its lower half as the pending work of l == 3 ----------------------------------------
@@ -1833,17 +1849,21 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             for (int l = 0; l < 5; l++) {   // (straight-line code instead of this loop: 1.5 KB of scratch spills -- tried)
                 const float *bias = cst + C_BETA + l * HID;
                 const float *bias_pend = l == 0 ? bias1 : bias - HID;   // the previous layer's (its lower half is pending)
+                // the trunk's packed weights carry 2^TRUNK_SHIFT (pack_kernel): its accumulators are descaled in the bias fma.
+                // (this layer is fc_(l+2), the pending one fc_(l+1); literals per branch -- as run-time scalars they cost spills)
+                constexpr float tk = TRUNK_K;
                 if constexpr (CT == 6) {   // colour layers: f16 Whi.Xhi + fp6 corrections (layer8x)
-                    if (l == 2) layer8x<DBG, 0, false, true>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
-                    else if (l == 3) layer8x<DBG, 1, true, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
-                    else if (l == 4) layer8x<DBG, 2, false, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part);
-                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                    if (l == 2) layer8x<DBG, 0, false, true>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part, tk, tk);
+                    else if (l == 3) layer8x<DBG, 1, true, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part, 1.f, tk);
+                    else if (l == 4) layer8x<DBG, 2, false, false>(lds, r, bh, bl, mx, acc, bias, bias_pend, wsig, h, part, 1.f, 1.f);
+                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part, tk, tk);
                 } else {
                     // fc_4's upper half feeds fc_5, fc_5's activations feed fc_5 / fc_6: no lo parts when those are 2-term
-                    if (l == 2) layer8<DBG, 16, true, false, true, 3, true, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
-                    else if (l == 3) layer8<DBG, 16, true, true, false, CT, CT == 3, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
-                    else if (CT != 3 && l == 4) layer8<DBG, 16, true, false, false, CT, CT == 3, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
-                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part);
+                    if (l == 2) layer8<DBG, 16, true, false, true, 3, true, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part, tk, tk);
+                    else if (l == 3) layer8<DBG, 16, true, true, false, CT, CT == 3, CT == 3>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part, 1.f, tk);
+                    else if (CT != 3 && l == 4) layer8<DBG, 16, true, false, false, CT, CT == 3, true>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part, 1.f, 1.f);
+                    else if (l == 4) layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part, 1.f, 1.f);
+                    else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part, tk, tk);
                 }
                 seg_tick<DBG>(lds, 2 + l, t_seg);
             }
@@ -2784,6 +2804,8 @@ int sdn_field_collapse_table(const float *embeddings, const int32_t *offsets_hos
     hipLaunchKernelGGL(collapse_kernel, dim3(sdn::div_up<uint32_t>(T, 256), L), dim3(256), 0, (hipStream_t)stream, p);
     return sdn::check_launch("sdn_field_collapse_table");
 }
+
+int sdn_field_trunk_shift(void) { return TRUNK_SHIFT; }
 
 int sdn_field_pack_weights(const float *w1, const float *const *wh5_host, const float *wc, void *packed,
                            sdn_stream_t stream) {

@@ -1,6 +1,7 @@
 """Host side of the fused field renderer (csrc/field.hip): per-scene / per-style preparation and the
 per-frame encode -> mlp launches.  PyTorch only provides device memory and the stream."""
 import ctypes
+import math
 import os
 
 import numpy as np
@@ -71,6 +72,20 @@ def prepare_scene(R):
     return R._fused_scene
 
 
+TRUNK_F16_HEADROOM = 32768.0   # largest |packed trunk weight| accepted (f16 overflows at 65504)
+
+
+def check_trunk_range(w1, trunk_hidden, shift):
+    """The packed trunk weights (fc_1 .. fc_4) carry 2^shift (field.hip pack_kernel): refuse a style whose weights would
+    leave f16's range there instead of rendering infinities.  One device->host read per style."""
+    tops = [float(w1.abs().max())] + [float(t.abs().max()) * 0.4 for t in trunk_hidden]
+    m = max(tops) if all(math.isfinite(v) for v in tops) else float("nan")
+    if not math.isfinite(m) or m * 2.0 ** shift >= TRUNK_F16_HEADROOM:
+        raise RuntimeError(f"field MLP trunk weights reach {m:.4g}: times 2^{shift} (the packed stream's scale) that leaves "
+                           f"f16's range; this style cannot be rendered by the MFMA field kernel")
+    return m
+
+
 def prepare_style(R):
     """Pack the folded MLP weights into MFMA fragment order + build the fp32 constant block (once per style).  Two images
     of the stream: the 3-term f16 split everywhere, and the one with the colour layers as f16 + fp6 (colour_terms = 6)."""
@@ -82,6 +97,8 @@ def prepare_style(R):
     ptrs = (ctypes.c_void_p * 5)(*[t.data_ptr() for t in wh])
     w1 = w["render_net.fc_1.weight"].contiguous()
     wc = w["render_net.fc_out_c.weight"].contiguous()
+    shift = lib.sdn_field_trunk_shift()
+    check_trunk_range(w1, wh[:3], shift)
     with torch.cuda.device(R.dev):
         rc = lib.sdn_field_pack_weights(w1.data_ptr(), ptrs, wc.data_ptr(), packed.data_ptr(), _stream(R.dev))
         capi.check(rc, "sdn_field_pack_weights")
@@ -95,7 +112,7 @@ def prepare_style(R):
     consts[off[2]:off[2] + 256] = w["render_net.fc_sigma.weight"].reshape(-1) * 0.4
     consts[off[3]:off[3] + 64] = w["render_net.fc_out_c.bias"]
     consts[off[4]] = w["render_net.fc_sigma.bias"].reshape(-1)[0]
-    R._fused_style = dict(packed=packed, packed_mx=packed_mx, consts=consts, sky_off=off[5], keep=wh)
+    R._fused_style = dict(packed=packed, packed_mx=packed_mx, consts=consts, sky_off=off[5], keep=wh, trunk_shift=shift)
     return R._fused_style
 
 

@@ -118,7 +118,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/sdnative.h but not exported"
     assert set(capi.declared_symbols()) <= set(declared)
-    assert lib.sdn_abi_version() == 3
+    assert lib.sdn_abi_version() == 4
 
 
 def _header_prototypes():
@@ -397,3 +397,21 @@ def test_precision_decisions_follow_the_measurements():
     R.cnn_auto_bound = 1e-7
     R.adopt_precision(meas())
     assert R.cnn_calibration["terms3x3"] == 3 and R.cnn_calibration["bound"] == 1e-7
+
+
+def test_trunk_weight_range_is_checked_before_packing():
+    """The packed trunk weights carry 2^sdn_field_trunk_shift(): a style whose weights would leave f16's range there is
+    refused with a message instead of rendering infinities."""
+    import torch
+    from scenedreamer_amd import capi, fused
+    shift = capi.lib().sdn_field_trunk_shift()
+    assert 0 <= shift <= 12
+    w1 = torch.full((256, 128), 0.05)
+    hidden = [torch.full((256, 256), 0.1) for _ in range(3)]
+    assert fused.check_trunk_range(w1, hidden, shift) == pytest.approx(0.05)
+    hidden[1][3, 7] = -fused.TRUNK_F16_HEADROOM / 0.4 / 2.0 ** shift * 1.01
+    with pytest.raises(RuntimeError, match="leaves f16's range"):
+        fused.check_trunk_range(w1, hidden, shift)
+    w1[0, 0] = float("nan")
+    with pytest.raises(RuntimeError):
+        fused.check_trunk_range(w1, [torch.zeros(2, 2)] * 3, shift)
