@@ -953,10 +953,12 @@ FIELD_NOMINAL_ERR = 2e-4   # field error charged to the budget when no field_gat
 # calibrate_style (the renderer's end-to-end gates; the north star's tolerance is 1e-3 abs on radiance and on the image):
 COLOUR_AUTO_BOUND = 1e-4   # largest net_out difference fp6-corrected vs 3-term colour layers (goldens: 4e-5)
 FIELD_AUTO_BOUND = 1e-3    # largest net_out error of the fused field vs the fp32 op sequence, whole frame: the north star's radiance
-                           # tolerance itself.  Measured on the synthetic weights (tools/gate_survey.py, tools/dbg_field_err.py,
-                           # profiles/r04_gate_survey.jsonl): max over the 36 M values of a 960x540 frame 5.6 - 8.2e-4 depending on the
-                           # pose (rms 2e-5; ~80 values above 5e-4): the density head sums ~2e3 x its result in cancelling terms, so the
-                           # 22-bit operands of the 3-term split put ~1e-3 on sigma where fp32 itself (vs fp64) is off by 1.4e-4
+                           # tolerance itself.  Measured on the synthetic weights (tools/dbg_field_err.py): max over the 36 M values of
+                           # a 960x540 frame 5 - 6e-5 (rms 4e-6) without early termination, 9e-5 with the default term_eps -- since the
+                           # trunk weights are packed times 2^8 (field.hip TRUNK_SHIFT; before that 5.6 - 8.2e-4, profiles/
+                           # r04_gate_survey.jsonl: the lo halves of the split sat in f16's subnormal range, ~20 significant bits, and
+                           # the density head sums ~2e3 x its result in cancelling terms).  The kernel's sigma is now as close to an
+                           # fp64 evaluation as PyTorch's fp32 one is (1e-4 both).
 IMAGE_AUTO_BOUND = 8e-4    # largest image error of the whole fused path vs the fp32 path, whole frame
 SKY_AUTO_BOUND = 2e-4      # largest sky_c error (vs PyTorch fp32) at which the sky MLP's hidden layers run as f16 + fp6 corrections
 CAL_MAX_PIXELS = 1 << 20   # frames above this many pixels are calibrated at a reduced resolution (same pose)
