@@ -415,3 +415,33 @@ def test_trunk_weight_range_is_checked_before_packing():
     w1[0, 0] = float("nan")
     with pytest.raises(RuntimeError):
         fused.check_trunk_range(w1, [torch.zeros(2, 2)] * 3, shift)
+
+
+def test_f16_split_loses_bits_to_subnormals_unless_the_weights_are_scaled():
+    """Why pack_kernel stores the trunk weights times 2^TRUNK_SHIFT (field.hip): the lo half of the 3-term split of a weight of
+    magnitude 0.03 lies in f16's subnormal range.  Emulated with numpy's float16 (which keeps subnormals, like the MFMA
+    operands) on four 256 -> 256 layers with fp64 accumulation, so that only the operand representation differs."""
+    rng = np.random.default_rng(0)
+
+    def split(v, shift=0):
+        v = v * 2.0 ** shift
+        hi = v.astype(np.float16).astype(np.float64)
+        return hi, (v - hi).astype(np.float32).astype(np.float16).astype(np.float64)
+
+    def run(shift):
+        x = rng.standard_normal((512, 256)).astype(np.float32).astype(np.float64)
+        ref = x.copy()
+        for _ in range(4):
+            W = (rng.standard_normal((256, 256)) * 0.0625 * 0.4).astype(np.float32).astype(np.float64)
+            b = rng.standard_normal(256) * 0.1
+            yr = ref @ W.T + b
+            ref = 1.5 * yr + np.abs(yr)
+            (wh, wl), (xh, xl) = split(W, shift), split(x)
+            y = (xh @ wh.T + xh @ wl.T + xl @ wh.T) * 2.0 ** -shift + b      # the three products of the kernel, descaled at the bias
+            x = (1.5 * y + np.abs(y)).astype(np.float32).astype(np.float64)
+        return float(np.abs(x - ref).mean() / np.abs(ref).mean())
+
+    rng = np.random.default_rng(0); plain = run(0)
+    rng = np.random.default_rng(0); scaled = run(8)
+    assert plain > 4 * scaled, (plain, scaled)          # measured: 1.1e-6 vs 1.3e-7
+    assert scaled < 3e-7                                 # below what fp32 operands give (4.6e-7)
