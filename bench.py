@@ -343,7 +343,8 @@ def other_configs(args, R, weights, scene, poses, dev):
             last = imgs[-1]
             field_ms = float(np.mean([a.elapsed_time(b) for a, b in probe["mlp_kernel"][1:]])) if probe.get("mlp_kernel") else None
             B, hit, ev = R.field_work(sel[1:], hw, ns, "minimal")
-            field_frac = (ev["evaluated_samples"] * 754176 / (field_ms * 1e-3) / 1e12 / 2500.0) if field_ms else None
+            flop = ev["evaluated_samples"] * (754176 - 294912) + ev.get("colour_samples", ev["evaluated_samples"]) * 294912
+            field_frac = (flop / (field_ms * 1e-3) / 1e12 / 2500.0) if field_ms else None
             how = "render_frames (pipelined trajectory loop, minimal apron), 1 warm-up frame"
         else:
             sdist.render_frame_tile_parallel(R, sel[0], hw, ns, mode="fused")

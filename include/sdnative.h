@@ -255,7 +255,14 @@ typedef struct sdn_field_aux {
     float *colour;       /* dev f32 [n_rays, num_samples, 64] */
     float *sky_blended;  /* dev f32 [n_rays, 64]              */
     uint8_t *nosky;      /* dev u8  [n_rays]                  */
+    /* the two below are diagnostics and do NOT switch the launch to the per-sample-output form: */
+    uint8_t *colour_passes; /* dev u8 [ceil(n_rays / 32)]: how many passes of each 32-ray group evaluated the colour branch */
+    int32_t flags;          /* SDN_FIELD_* bits */
 } sdn_field_aux;
+/* Colour-branch skipping: a pass (4 samples of each of a workgroup's 32 rays) whose 128 samples ALL have relu(sigma) * dist == 0
+ * -- volume-rendering weight exactly 0, mc_utils.py:154-161 -- does not evaluate fc_5 / fc_6 / fc_out_c: the colours would be
+ * multiplied by zero, net_out is bit-identical.  On by default; this flag evaluates every pass in full (A/B timing, tests). */
+#define SDN_FIELD_NO_COLOUR_SKIP 1
 int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,

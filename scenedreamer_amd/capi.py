@@ -94,7 +94,11 @@ class SdnError(RuntimeError):
 
 class FieldAux(ctypes.Structure):
     """sdn_field_aux (include/sdnative.h): optional device pointers for the other return values of Generator._forward_perpix."""
-    _fields_ = [("weights", c_p), ("depth", c_p), ("sigma", c_p), ("colour", c_p), ("sky_blended", c_p), ("nosky", c_p)]
+    _fields_ = [("weights", c_p), ("depth", c_p), ("sigma", c_p), ("colour", c_p), ("sky_blended", c_p), ("nosky", c_p),
+                ("colour_passes", c_p), ("flags", ctypes.c_int32)]
+
+
+FIELD_NO_COLOUR_SKIP = 1     # sdn_field_aux.flags (include/sdnative.h)
 
 
 def lib():

@@ -162,6 +162,8 @@ struct MlpParams {
     float *skyb_out;           // [R][64]     skynet_out_c after the keep_sky_out blend with sky_avg (:401)
     uint8_t *nosky_out;        // [R]         nosky_mask (:382-383)
     float *sigma_out;          // MODE_RAW: [R] density fc_sigma(f) of every row (LightningMLP.forward's first output)
+    uint8_t *colour_passes;    // optional [ceil(n_tiles / 4)]: passes of every 32-ray group that ran the colour branch (tests / bench)
+    int32_t no_colour_skip;    // field_kernel: 1 = evaluate fc_5 / fc_6 / fc_out_c in every pass (A/B switch; the results are identical)
 };
 
 // mlp_kernel's input / output modes
@@ -874,6 +876,18 @@ __device__ __forceinline__ int ring_acquire(char *lds, Ring &r) {
     return pos;
 }
 
+// The rest of this pass's weight stream is not needed (colour branch skipped): the DMA_AHEAD slots in flight hold its next
+// layer.  Refill their ring positions with the first slots of the NEXT pass, exactly the state the kernel starts in.  Every
+// wave owns its quarter of a slot for both the stale and the new pieces; the wait lets the stale ones land first (they were
+// issued a whole layer ago: nothing is waited for in practice).  No barrier: nobody reads the positions being refilled, and the
+// position of the last consumed slot (which slower waves may still be reading) is not touched.
+__device__ __forceinline__ void ring_restart(char *lds, Ring &r) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int sl = 0; sl < DMA_AHEAD; sl++) ring_issue(lds, r, r.g + sl, sl);
+    r.next_in_pass = DMA_AHEAD;
+}
+
 // Per-lane view of a 256-vector in the C/D register layout: element (IB, Q, e) is feature
 // 32*IB + 16*Q + (e&3) + 8*(e>>2) + 4*h.
 // LDS reads of the small constant tables are issued through inline asm: hipcc's waitcnt pass cannot tell them
@@ -1066,6 +1080,35 @@ __device__ __forceinline__ void act_step(const f32x16 (&acc)[8], const float *bi
                                          half8 (&bl)[16], float &part, float k = 1.f) {
     act_half<T, 0, SIG>(acc, bias, wsig, h, bh, bl, part, k);
     act_half<T, 1, SIG>(acc, bias, wsig, h, bh, bl, part, k);
+}
+
+// The density head's contribution of a finished layer's LOWER half (fragments 8..15 = accumulators acc[4..7]) without producing
+// the fragments: stages 0..3 of act_stage for half fragment J -- the very functions, in the very order, the next layer's pending
+// work runs later, so the sum is bit-identical to the one that layer accumulates.  mlp_kernel uses it to know sigma of a pass
+// BEFORE the colour layers start (colour-branch skipping).  The LDS reads of the bias / weight rows run one half fragment ahead.
+template <int J>
+__device__ __forceinline__ void sigma_half(const f32x16 (&acc)[8], const float *bias, const float *wsig, int h, half8 (&bh)[16],
+                                           half8 (&bl)[16], ActIn (&in)[2], float &part, float k) {
+    constexpr int T = 8 + J / 2, HS = J % 2;
+    if constexpr (J + 1 < 16) {
+        act_fetch<8 + (J + 1) / 2, (J + 1) % 2, true>(bias, wsig, h, in[(J + 1) & 1]);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(in[J & 1].b), "+v"(in[J & 1].w)::"memory");
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(in[J & 1].b), "+v"(in[J & 1].w)::"memory");
+    }
+    ActRegs g;
+    act_stage<T, HS, true, 0>(acc, in[J & 1], bh, bl, part, g);
+    act_stage<T, HS, true, 1>(acc, in[J & 1], bh, bl, part, g, k);
+    act_stage<T, HS, true, 2>(acc, in[J & 1], bh, bl, part, g);
+    act_stage<T, HS, true, 3>(acc, in[J & 1], bh, bl, part, g);
+}
+
+template <int... Js>
+__device__ __forceinline__ void sigma_lower_half(std::integer_sequence<int, Js...>, const f32x16 (&acc)[8], const float *bias,
+                                                 const float *wsig, int h, half8 (&bh)[16], half8 (&bl)[16], float &part, float k) {
+    ActIn in[2];
+    act_fetch<8, 0, true>(bias, wsig, h, in[0]);
+    (sigma_half<Js>(acc, bias, wsig, h, bh, bl, in, part, k), ...);
 }
 
 // One 8-row-block layer (NS k-steps) from the LDS ring.
@@ -1589,7 +1632,7 @@ __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], h
 
 // DBG & 512 (timing experiment, ablation builds): cycles of workgroup-thread 0 per segment of a pass, summed in LDS --
 // 0 inputs (encode stage / staging), 1 fc_1, 2..6 fc_2..fc_6, 7 fc_out_c, 8 volume rendering, 9 everything between passes of
-// different groups; 10 = passes.  s_memtime is an SMEM operation: the compiler waits lgkmcnt(0) for it, which is only stricter
+// different groups; 10 = passes; 11 = the colour-skip decision (early sigma + ballot), 12 = passes whose colour branch was skipped.  s_memtime is an SMEM operation: the compiler waits lgkmcnt(0) for it, which is only stricter
 // than the hand-counted LDS waits around it (segment boundaries have no fragment reads in flight).
 template <int DBG>
 __device__ __forceinline__ void seg_tick(char *lds, int idx, unsigned &tprev) {
@@ -1606,6 +1649,15 @@ __device__ __forceinline__ void seg_tick(char *lds, int idx, unsigned &tprev) {
 template <int DBG, int CT, int MODE = MODE_BUFFER>
 __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     constexpr bool FUSED = MODE == MODE_FUSED || MODE == MODE_FUSED_AUX, AUX = MODE == MODE_FUSED_AUX, RAW = MODE == MODE_RAW;
+    // Colour-branch skipping (field_kernel): a sample with relu(sigma) * dist == 0 has volume-rendering weight EXACTLY 0
+    // (mc_utils.py:154-161: weights = (1 - exp(-relu(sigma) * dists)) * T), so its colour is multiplied by zero; when that holds
+    // for all 128 samples of a workgroup's pass, fc_5 / fc_6 / fc_out_c (35 % of the pass's matrix instructions, 18 of its 46
+    // ring slots) are not evaluated at all -- net_out is bit-identical.  sigma is complete only after fc_4's lower half has
+    // been activated, which normally happens as fc_5's pending work: sigma_lower_half computes that half's contribution
+    // ahead on a copy of the running sum (a few % of a pass), the decision is a wave ballot combined over the 4 waves (they
+    // share the weight ring).  (Taking the decision inside fc_5, behind its pending work, costs nothing extra per pass but saves
+    // less per skipped pass -- measured on the same box: -4.8 % vs -6.9 % of the kernel time.)
+    constexpr bool SKIP = MODE == MODE_FUSED;
     __shared__ __attribute__((aligned(1024))) char lds[LDS_TOTAL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
@@ -1716,7 +1768,8 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
 
         float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float carry = 0.f, tsum = 0.f;
-        int n_done = 0;
+        int n_done = 0, n_colour = 0;
+        bool skip_test = SKIP && !p.no_colour_skip;     // (uniform) whether the next pass of this group takes the colour-skip decision at all
 
         for (int ch = 0; grp_hit && ch < p.nch; ch++) {
             const size_t tc = (size_t)(tile_ok ? tile : 0) * p.nch + ch;
@@ -1836,6 +1889,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             if constexpr (DBG & 512) asm volatile("s_waitcnt vmcnt(0)" ::"v"(bh[7]), "v"(bl[7]) : "memory");
             seg_tick<DBG>(lds, 0, t_seg);
             float part = 0.f;
+            bool colour_skipped = false;
             const float *wsig = cst + C_WSIGMA;
             // ---- fc_1: 8 k-steps; fragments 0..6 of its upper half are activated behind its own lower half, fragment 7
             //      right after it, its lower half behind fc_2's head ---------------------------------------------------
@@ -1866,7 +1920,50 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     else layer8<DBG, 16, true, false, false>(lds, r, bh, bl, acc, bias, bias_pend, wsig, h, part, tk, tk);
                 }
                 seg_tick<DBG>(lds, 2 + l, t_seg);
+                if constexpr (SKIP) {
+                    if (l == 2 && skip_test) {
+                        // sigma of this pass: `part` holds fc_4's upper half, the lower half's terms are added on a copy (fc_5's
+                        // pending work adds them to `part` itself, in the same order, if the pass goes on)
+                        float part_e = part;
+                        sigma_lower_half(std::make_integer_sequence<int, 16>{}, acc, bias, wsig, h, bh, bl, part_e, tk);
+                        const float sigma_e = part_e + __shfl_xor(part_e, 32) + cst[C_BSIGMA];
+                        const bool zero_w = !ray_ok || (flag & 1) || fmaxf(sigma_e, 0.f) * dist == 0.f;
+                        const int wave_zero = __popcll(__ballot(zero_w));          // lanes: 2 per sample
+                        // ONE barrier: flags[8..11] are written only here, and a wave reaches its next write only through the ring
+                        // barriers of at least one whole layer, which nobody passes before having read these
+                        if (lane == 0) flags[8 + wave] = wave_zero;
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        const int grp_zero = __builtin_amdgcn_readfirstlane(flags[8] + flags[9] + flags[10] + flags[11]);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        seg_tick<DBG>(lds, 11, t_seg);
+                        // Whether a pass is empty hardly depends on the depth along the rays (measured on the benchmark frames,
+                        // tools/dbg_sigma_stats.py: P(next pass of the group empty | this one empty) = 0.89 - 0.93, | this one less
+                        // than 3/4 empty: 0.000 - 0.002), so a group stops taking the decision -- the work of computing sigma
+                        // ahead -- after a pass that was not at least 3/4 empty.  Purely a cost heuristic: net_out cannot change.
+                        // (Tried on top: a WAVE whose own 32 samples are empty sitting the colour layers out while the others work --
+                        //  barriers and its share of the ring DMA only.  Same box: 15.03 -> 15.55 ms, 18.49 -> 19.08 ms: the idle
+                        //  SIMD buys the other three nothing, the extra decisions cost.  Not kept.)
+                        skip_test = grp_zero >= 192;
+                        if (grp_zero == 256) { colour_skipped = true; break; }
+                    }
+                }
             }
+            if constexpr (SKIP) {
+                if (colour_skipped) {
+                    // every weight of the pass is exactly zero: carry, tsum and outq would all be incremented by +0
+                    ring_restart(lds, r);
+                    if constexpr (DBG & 512) {
+                        if (threadIdx.x == 0) {
+                            reinterpret_cast<unsigned *>(lds + LDS_TIMERS)[10] += 1u;
+                            reinterpret_cast<unsigned *>(lds + LDS_TIMERS)[12] += 1u;
+                        }
+                    }
+                    n_done = ch + 1;
+                    continue;   // (no termination ballot: the transmittances did not change since the last one)
+                }
+            }
+            n_colour++;
             // ---- fc_out_c ------------------------------------------------------------------------------------------
             {   // inputs of the next pass of this wave: the next step of this tile, or the first step of its next group
                 long tn = tc_s + 1;
@@ -1996,6 +2093,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         }
 #endif
         if (p.passes && threadIdx.x == 0) p.passes[grp] = (uint8_t)n_done;   // passes this group went through (tests / bench)
+        if (p.colour_passes && threadIdx.x == 0) p.colour_passes[grp] = (uint8_t)n_colour;   // ... and how many of them ran the colour branch
 
         // ---- blend the sky, store ---------------------------------------------------------------------------------
         if constexpr (!RAW) {
@@ -2049,7 +2147,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     }
     if constexpr (DBG & 512) {   // per-segment cycles of this workgroup's thread 0 into its first net_out row (floats 3..13)
         __syncthreads();
-        if (threadIdx.x < 11) p.net_out[(size_t)(blockIdx.x * 4) * OUTC + 3 + threadIdx.x] = (float)reinterpret_cast<unsigned *>(lds + LDS_TIMERS)[threadIdx.x];
+        if (threadIdx.x < 13) p.net_out[(size_t)(blockIdx.x * 4) * OUTC + 3 + threadIdx.x] = (float)reinterpret_cast<unsigned *>(lds + LDS_TIMERS)[threadIdx.x];
     }
     if constexpr (DBG & 128) {   // timing experiment: (input-staging cycles, total cycles, passes) of this wave into net_out
         if (lane == 0) {
@@ -2935,6 +3033,7 @@ static int fill_mlp(MlpParams &p, const char *who, const void *packed, const flo
     p.passes = passes;
     p.cam_ori_dev = nullptr; p.w_out = nullptr; p.depth_out = nullptr; p.sigma_out = nullptr;
     p.sig_out = nullptr; p.col_out = nullptr; p.skyb_out = nullptr; p.nosky_out = nullptr;
+    p.colour_passes = nullptr; p.no_colour_skip = 0;
     p.feat = nullptr; p.dist = nullptr; p.label = nullptr; p.rayflag = nullptr;
     p.wpk = (const half8 *)packed;
     p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
@@ -3023,6 +3122,10 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
         p.w_out = aux->weights; p.depth_out = aux->depth; p.sig_out = aux->sigma; p.col_out = aux->colour;
         p.skyb_out = aux->sky_blended; p.nosky_out = aux->nosky;
     }
+    if (aux) {   // (these two do not select the per-sample-output instantiation)
+        p.colour_passes = aux->colour_passes;
+        p.no_colour_skip = (aux->flags & SDN_FIELD_NO_COLOUR_SKIP) ? 1 : 0;
+    }
     SDN_REQUIRE(colour_terms != 2, "sdn_field_render: colour_terms must be 3 or 6 (the 2-term profile exists for sdn_field_mlp only)");
     const int wg = mlp_workgroups(p, n_workgroups);
 #ifdef SDN_MLP_ABLATION
@@ -3056,6 +3159,7 @@ int sdn_render_mlp(const float *x, const uint8_t *label, const void *packed, con
     p.sky_avg = nullptr; p.ticket = ticket;
     p.cam_ori_dev = nullptr; p.w_out = nullptr; p.depth_out = nullptr; p.sigma_out = sigma;
     p.sig_out = nullptr; p.col_out = nullptr; p.skyb_out = nullptr; p.nosky_out = nullptr;
+    p.colour_passes = nullptr; p.no_colour_skip = 0;
     p.enc = EncParams{};
     const int wg = mlp_workgroups(p, n_workgroups);
     if (colour_terms == 6) hipLaunchKernelGGL((mlp_kernel<0, 6, MODE_RAW>), dim3(wg), dim3(256), 0, (hipStream_t)stream, p);

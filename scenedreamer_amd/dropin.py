@@ -57,6 +57,15 @@ class GeneratorBinding:
         self._scene_key = None
         self._frame = None          # the frame evaluated once for all of its tiles (frame_field)
         self.coalesce = True
+        self._refused = None        # (style key, message): prepare_style refused this style (TrunkRangeError) -- not retried per tile
+
+    def release(self, G=None):
+        """Drop the frame-sized device buffers this binding pins between calls (net_out / image of the last coalesced frame
+        and, with `G`, the sky features its sky_net keeps for the frame's tiles): ~150 MB each at 960x540.  They are
+        replaced, never accumulated, while rendering; call this when a generator stays alive after its last frame."""
+        self._frame = None
+        if G is not None:
+            G.sky_net.__dict__.pop("_sdn_last_frame", None)
 
     # ------------------------------------------------------------------ what the fused kernel implements
     def why_not_perpix(self, G, voxel_id, depth2, raydirs, cam_ori_t, z, global_enc):
@@ -124,6 +133,23 @@ class GeneratorBinding:
         B.style("render_net.", z, 0, fold_render_net)
         B.style("sky_net.", z, 0, modules.fold_sky_net)
 
+    def style_refusal(self):
+        """None, or why the packed weight stream cannot hold the current style (fused.TrunkRangeError: trunk weights beyond
+        f16's range once scaled).  Checked after sync(); one device -> host read per STYLE (prepare_style), then cached."""
+        B = self.B
+        key = (B._zkey.get("render_net."), B._bound["render_net."][1])
+        if self._refused is not None and self._refused[0] == key:
+            return self._refused[1]
+        self._refused = None
+        if B._fused_style is None:
+            try:
+                fused.prepare_style(B)
+            except fused.TrunkRangeError as e:
+                self._refused = (key, "trunk weights outside the packed f16 range")
+                self._refused_detail = str(e)
+                return self._refused[1]
+        return None
+
     # ------------------------------------------------------------------ rays of the call
     @staticmethod
     def frame_window(voxel_id, depth2, raydirs):
@@ -147,7 +173,7 @@ class GeneratorBinding:
                 return None
             pitch = sv[1] // M
         else:
-            pitch = w
+            pitch = w                                        # a one-row tile does not show the frame's row pitch: rays() looks it up
         ov, od, orr = voxel_id.storage_offset(), depth2.storage_offset(), raydirs.storage_offset()
         if ov % M or od != ov or orr * M != ov * 3:          # the same tile of all three frames
             return None
@@ -173,6 +199,14 @@ class GeneratorBinding:
             if (last["rd_ptr"] == pr and last["n_rays"] == win.n_src and last["rd_version"] == raydirs._version and
                     last["zkey"] is not None and last["zkey"] == B._zkey.get("sky_net.") and
                     last["wkey"] == modules.Backend.tensors_key(G.sky_net)):
+                if h == 1:
+                    # the frame's row pitch is read off the pre-pass's ray directions ([1,H0,W0,1,3], scenedreamer.py:592-598);
+                    # unknown -> the tile is evaluated in place but never treated as a window of a coalesced frame
+                    shp = tuple(last["rd_ref"].shape)
+                    W0 = shp[2] if len(shp) == 5 and shp[0] == 1 and shp[1] * shp[2] == win.n_src else 0
+                    win.pitch_known = W0 >= w and (win.first % W0) + w <= W0 if W0 else False
+                    if win.pitch_known:
+                        win.pitch = W0
                 self.stats["tiles_in_place"] += 1
                 self.stats["sky_reused"] += 1
                 return win, pv, pd, pr, last["sky_c"], last
@@ -230,14 +264,15 @@ class GeneratorBinding:
         if hb + h > H0 or wb + w > W0:
             return None
         B = self.B
-        zkey = (z.data_ptr(), z._version)
-        if fr["img"] is None or fr.get("img_key") != (zkey, B._bound.get("denoiser.", (None, None))[1]):
+        zkey = (z.data_ptr(), z._version)       # (fr["img_z"] holds the keyed tensor: its address cannot be recycled meanwhile)
+        if fr["img"] is None or fr.get("img_z") is None or fr.get("img_key") != (zkey, B._bound.get("denoiser.", (None, None))[1]):
             B.bind("denoiser.", G.denoiser)
             B.style("denoiser.", z, 0, fold_denoiser)
             raw = torch.empty((1, 3, H0, W0), dtype=torch.float32, device=full.device)
             fr["img"] = B.mfma_cnn(full)(full, raw=raw)
             fr["raw"] = raw
             fr["img_key"] = (zkey, B._bound["denoiser."][1])
+            fr["img_z"] = z
         self.stats["cnn_tiles_from_frame"] += 1
         return fr["img"][:, :, hb:hb + h, wb:wb + w], fr["raw"][:, :, hb:hb + h, wb:wb + w]
 
@@ -260,12 +295,18 @@ def _render_net_reason(net):
     return None
 
 
-def binding(G, aux=None):
+def binding(G, aux=None, term_eps=None):
+    """The generator's GeneratorBinding (created on first use).  aux: also produce the other eleven return values of
+    _forward_perpix.  term_eps: early ray termination threshold of the field kernel for this generator (0 = evaluate every
+    sample exactly like the reference; default fused.TERM_EPS_DEFAULT, which moves net_out by at most 2 x eps = 1e-4)."""
     b = G.__dict__.get("_sdn_binding")
     if b is None:
         b = G.__dict__["_sdn_binding"] = GeneratorBinding()
     if aux is not None:
         b.aux = bool(aux)
+    if term_eps is not None:
+        b.B.term_eps = float(term_eps)
+        b._frame = None
     return b
 
 
@@ -290,6 +331,13 @@ def fast_forward_perpix(self, blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z
     B = b.B
     with torch.no_grad():
         b.sync(self, z, global_enc)
+        why = b.style_refusal()
+        if why is not None:
+            b.stats["perpix_fast"] -= 1
+            _count(b, "perpix_reference", why)
+    if why is not None:
+        return self._forward_perpix_reference(blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z, global_enc)
+    with torch.no_grad():
         _, h, w, M, _ = voxel_id.shape
         ns = int(self.num_samples)
         win, vid, d2, rd, sky_c, sky_mean = b.rays(self, voxel_id, depth2, raydirs)
@@ -303,7 +351,7 @@ def fast_forward_perpix(self, blk_feats, voxel_id, depth2, raydirs, cam_ori_t, z
         aux = dict.fromkeys(fused.AUX_OUTPUTS) if b.aux else None
         out = [None] * len(PERPIX_OUTPUTS)
         if (b.coalesce and isinstance(sky_mean, dict) and u is None and aux is None and hasattr(self, "sky_avg") and
-                win.rows * win.cols < win.n_src):
+                win.rows * win.cols < win.n_src and getattr(win, "pitch_known", True)):
             # a tile of a frame whose arrays (and sky features) are all at hand: the frame is evaluated once, tiles are views
             full = b.frame_field(self, sky_mean, win, (vid, d2, rd), (voxel_id, depth2, raydirs), cam_ori_t, sky_avg, ns)
             hb, wb = divmod(win.first, win.pitch)
@@ -364,7 +412,7 @@ def fast_forward_global(self, net_out, z):
 # ---------------------------------------------------------------------------------------------------------------------
 # installation
 # ---------------------------------------------------------------------------------------------------------------------
-def accelerate(G, aux=False):
+def accelerate(G, aux=False, term_eps=None):
     """Bind the fast path to an existing reference generator: the classes of its render_net / sky_net / denoiser get the
     native forwards (parameters untouched), its _forward_perpix / _forward_global become the methods above."""
     for name in ("render_net", "sky_net", "denoiser"):
@@ -375,7 +423,7 @@ def accelerate(G, aux=False):
         G._forward_global_reference = types.MethodType(cls._forward_global, G)
         G._forward_perpix = types.MethodType(fast_forward_perpix, G)
         G._forward_global = types.MethodType(fast_forward_global, G)
-    binding(G, aux=aux)
+    binding(G, aux=aux, term_eps=term_eps)
     return G
 
 

@@ -75,14 +75,19 @@ def prepare_scene(R):
 TRUNK_F16_HEADROOM = 32768.0   # largest |packed trunk weight| accepted (f16 overflows at 65504)
 
 
+class TrunkRangeError(RuntimeError):
+    """prepare_style: this style's trunk weights do not fit the packed f16 stream.  The explicit Renderer API lets it
+    propagate; the drop-in surfaces (modules.py, dropin.py) catch it and evaluate the call with the reference's own method."""
+
+
 def check_trunk_range(w1, trunk_hidden, shift):
     """The packed trunk weights (fc_1 .. fc_4) carry 2^shift (field.hip pack_kernel): refuse a style whose weights would
     leave f16's range there instead of rendering infinities.  One device->host read per style."""
     tops = [float(w1.abs().max())] + [float(t.abs().max()) * 0.4 for t in trunk_hidden]
     m = max(tops) if all(math.isfinite(v) for v in tops) else float("nan")
     if not math.isfinite(m) or m * 2.0 ** shift >= TRUNK_F16_HEADROOM:
-        raise RuntimeError(f"field MLP trunk weights reach {m:.4g}: times 2^{shift} (the packed stream's scale) that leaves "
-                           f"f16's range; this style cannot be rendered by the MFMA field kernel")
+        raise TrunkRangeError(f"field MLP trunk weights reach {m:.4g}: times 2^{shift} (the packed stream's scale) that leaves "
+                              f"f16's range; this style cannot be rendered by the MFMA field kernel")
     return m
 
 
@@ -243,8 +248,17 @@ def single_kernel(R):
 SINGLE_KERNEL_DEFAULT = "1"   # same frame time as the two-kernel sequence (A/B), without its 10.8 GB/frame of HBM hand-off
 
 
+def colour_skip(R):
+    """Whether field_kernel skips the colour branch of passes whose 128 samples all have volume-rendering weight exactly zero
+    (csrc/field.hip; bit-identical output).  Renderer.colour_skip, else SDN_COLOUR_SKIP, else on."""
+    v = getattr(R, "colour_skip", None)
+    if v is None:
+        v = os.environ.get("SDN_COLOUR_SKIP", "1") not in ("0", "", "false")
+    return bool(v)
+
+
 def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=None, window=None, division="reciprocal",
-                 net_out=None, aux=None):
+                 net_out=None, aux=None, colour_passes=None):
     """The whole field of a ray set in one launch (csrc/field.hip field_kernel): sample placement + hash-grid lookup + render
     MLP + compositing.  Same arguments and the same bits as field_fused's encode -> mlp sequence; no feature buffer, so no
     ray chunking at any frame size.
@@ -253,7 +267,9 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
     cam_ori: host values, or a CUDA tensor -- then the kernel reads it from device memory (no device -> host copy).
     aux: None, or a dict: its keys (any of AUX_OUTPUTS: "weights", "depth", "sigma" [n_rays, ns], "colour" [n_rays, ns, 64],
     "sky_blended" [n_rays, 64], "nosky" u8 [n_rays]; an empty dict = "weights" + "depth") name the other return values of
-    Generator._forward_perpix the launch should also produce; the dict receives the tensors."""
+    Generator._forward_perpix the launch should also produce; the dict receives the tensors.
+    passes / colour_passes: optional u8 [ceil(n_rays / 32)] -- passes every 32-ray group went through / how many of them
+    evaluated the colour branch (see colour_skip)."""
     sc = R._fused_scene or prepare_scene(R)
     st = R._fused_style or prepare_style(R)
     ct, eps = precision_profile(R)
@@ -306,6 +322,11 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
         for k in want:
             aux[k] = torch.empty(shapes[k][0], dtype=shapes[k][1], device=R.dev)     # (with aux the kernel visits every ray and sample)
         aux_c = capi.FieldAux(**{k: aux[k].data_ptr() for k in want})
+    skip = colour_skip(R)
+    if colour_passes is not None or not skip:
+        aux_c = aux_c or capi.FieldAux()
+        aux_c.colour_passes = colour_passes.data_ptr() if colour_passes is not None else None
+        aux_c.flags = 0 if skip else capi.FIELD_NO_COLOUR_SKIP
     with torch.cuda.device(R.dev):
         rc = _lib().sdn_field_render(p_vid, p_d2, p_rd, sc["lut"].data_ptr(), sc["table3"].data_ptr(),
                                      sc["T"], sc["scales"].data_ptr(), sc["genc"].ctypes.data, ori.ctypes.data,

@@ -24,7 +24,6 @@ Two ways in:
   * the stand-alone classes below, for use without the reference's Python tree.
 """
 import itertools
-import os
 
 import numpy as np
 import torch
@@ -52,6 +51,7 @@ class Backend:
         self.cnn_calibration = None
         self._bound = {}
         self._zkey = {}
+        self._zref = {}     # the style tensor each _zkey was taken from, kept ALIVE: see style()
 
     @staticmethod
     def tensors_key(module):
@@ -78,6 +78,7 @@ class Backend:
         self.dev = dev
         self._bound[prefix] = (module, key)
         self._zkey.pop(prefix, None)
+        self._zref.pop(prefix, None)
         if prefix == "denoiser.":
             self.__dict__.pop("_mfma_cnns", None)   # packed convolution weights
             self.cnn_calibration = None
@@ -86,11 +87,18 @@ class Backend:
         return True
 
     def style(self, prefix, z, item, fold):
-        """Fold style code z[item] for the network under `prefix` unless that very tensor content was folded already."""
-        key = (z.data_ptr(), z._version, tuple(z.shape), item)
-        if self._zkey.get(prefix) != key:
+        """Fold style code z[item] for the network under `prefix` unless that very tensor content was folded already.
+
+        "Already" = same address, same version counter, same shape -- which only means "same content" while the tensor the
+        key was taken from is still alive: the reference builds `z = self.style_net(style)` afresh per call
+        (scenedreamer.py:505) and the caching allocator hands a freed z's address (version 0 again) to the next one.  So the
+        keyed tensor is HELD here (`_zref`); while it lives its storage cannot be recycled, and a tensor with the same address
+        can only be a view of the same storage, whose writes bump the shared version counter."""
+        key = (z.data_ptr(), z._version, tuple(z.shape), tuple(z.stride()), item)
+        if self._zkey.get(prefix) != key or self._zref.get(prefix) is None:
             fold(self, z[item:item + 1].detach().to(torch.float32).reshape(1, -1))
             self._zkey[prefix] = key
+            self._zref[prefix] = z
 
 
 def _backend(module):
@@ -137,6 +145,14 @@ class LightningMLPNative:
                 return f"fc_{i} is not a bias-free output-mode ModLinear"
         if z.dim() != 2 or z.shape[0] != x.shape[0]:
             return "z must be [N, style_dim]"
+        if self.use_seg and m.numel():
+            # the kernel replaces fc_m_a(m) by ONE row of fc_m_a^T (the label bias): only a one-hot m means that.  Anything
+            # else the reference accepts (soft / smoothed labels, an all-zero row) goes to the composite path -- one fused
+            # reduction and one device -> host read per call; the generator-level binding (dropin.py) builds the labels
+            # itself and does not come through here.
+            mf = m.reshape(-1, m.shape[-1])
+            if not bool(((mf.max(dim=-1).values == 1) & (mf.sum(dim=-1) == 1)).all()):
+                return "m is not one-hot"
         return None
 
     def forward(self, x, raydir, z, m):
@@ -157,15 +173,16 @@ class LightningMLPNative:
         with torch.no_grad():
             for i in range(n):
                 B.style("render_net.", z, i, fold_render_net)
-                st = B._fused_style or fused.prepare_style(B)
+                try:
+                    st = B._fused_style or fused.prepare_style(B)
+                except fused.TrunkRangeError as e:        # weights the packed f16 stream cannot hold: the reference's arithmetic
+                    self.__dict__["_sdn_composite_reason"] = str(e)
+                    return self._forward_composite(x, raydir, z, m)
                 ct, _ = fused.precision_profile(B)
                 xi = x[i].reshape(rows, 128).contiguous()
                 if self.use_seg:
                     # fc_m_a(m) for a ONE-HOT row is row `argmax` of fc_m_a^T (what scenedreamer.py:357-363 builds m for)
-                    mi = m[i].reshape(rows, 12)
-                    if os.environ.get("SDN_CHECK_ONEHOT"):
-                        if not bool(((mi.sum(-1) == 1) & (mi.max(-1).values == 1)).all()):
-                            raise ValueError("LightningMLP (native): `m` must be one-hot")
+                    mi = m[i].reshape(rows, 12)                       # one-hot: native_reason checked it
                     lab = mi.argmax(dim=-1).to(torch.uint8)
                 else:
                     lab = torch.zeros(rows, dtype=torch.uint8, device=x.device)

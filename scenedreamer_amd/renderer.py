@@ -533,7 +533,7 @@ class Renderer:
         o = crop - CNN_HALO if (apron == "minimal" and crop > CNN_HALO) else 0
         nch = -(-num_samples // 4)
         eps = fused.precision_profile(self)[1]
-        B = hits = groups = evald = skipped = 0.0
+        B = hits = groups = evald = skipped = coloured = 0.0
         with torch.no_grad():
             for pose in poses:
                 vid, d2, rd, (H0, W0) = self.cast_rays(pose, resolution_hw)
@@ -543,22 +543,25 @@ class Renderer:
                 B += n * num_samples
                 hits += float(hit.float().mean())
                 groups += float(g.float().mean())
-                if eps > 0 and fused.single_kernel(self):
+                if (eps > 0 or fused.colour_skip(self)) and fused.single_kernel(self):
                     n0 = H0 * W0
                     v, d, r = vid.view(n0, self.M), d2.view(2, n0, self.M), rd.view(n0, 3)
                     sky_c, sky_avg = fused.sky_fused(self, r)
                     win = fused.Window.crop(H0, W0, o)
                     pa = torch.zeros((win.n_rays + 31) // 32, dtype=torch.uint8, device=self.dev)
+                    cp = torch.zeros_like(pa)
                     fused.field_render(self, v, d, r, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, num_samples,
-                                       passes=pa, window=win)
+                                       passes=pa, window=win, colour_passes=cp)
                     executed = int(pa.sum(dtype=torch.int64))
                     evald += executed * 128
+                    coloured += int(cp.sum(dtype=torch.int64)) * 128
                     skipped += int((pa > 0).sum()) * nch - executed
                 else:
                     evald += int(g.sum()) * 32 * nch * 4
+                    coloured += int(g.sum()) * 32 * nch * 4
         k = max(1, len(poses))
         return B / k, hits / k, dict(group_hit_fraction=groups / k, evaluated_samples=evald / k, passes_skipped_by_termination=skipped / k,
-                                     passes_of_visited_groups=(evald / 128 + skipped) / k)
+                                     passes_of_visited_groups=(evald / 128 + skipped) / k, colour_samples=coloured / k)
 
     def roofline_records(self, B, ms_enc, ms_mlp, hit, ev, kernel, hbm_peak_gbps=8000.0, mfma_peak_tflops=2500.0, timing="",
                          field_kernel=False):
@@ -592,7 +595,11 @@ class Renderer:
         # ---- field MLP.  Algorithmic FLOPs are counted on the samples the kernel EVALUATES (it skips 32-ray groups that
         # hit nothing and the passes early termination removes): samples of skipped groups are not work done.
         n_eval = ev["evaluated_samples"]
-        ach_m = n_eval * 754176 / (ms_mlp * 1e-3) / 1e12
+        # ... and the colour branch (fc_5, fc_6, fc_out_c: 294 912 of the 754 176 FLOP) only on the passes that ran it: passes whose
+        # 128 samples all have volume-rendering weight exactly zero skip it (field.hip), and work not done is not counted
+        n_col = ev.get("colour_samples", n_eval)
+        flop_launch = n_eval * (754176 - 294912) + n_col * 294912
+        ach_m = flop_launch / (ms_mlp * 1e-3) / 1e12
         # MFMA issue slots per pass / algorithmic (one f16 MFMA per product tile): 2208 for the 3-term split everywhere;
         # colour layers 2-term: 2 x 128 fewer; colour layers f16 + fp6: 2 x (384 - 192) fewer (an fp6 K = 64 MFMA takes the
         # issue time of one K = 16 f16 MFMA)
@@ -604,6 +611,9 @@ class Renderer:
                "achieved": ach_m, "peak": mfma_peak_tflops, "unit": "TFLOP/s", "frac": ach_m / mfma_peak_tflops,
                "traffic": traffic.get("field_kernel (mlp_kernel<0, 6, 1>)" if field_kernel else "mlp_kernel"), "traffic_source": traffic_src,
                "samples_per_launch": B, "samples_evaluated": n_eval, "algorithmic_flop_per_sample": 754176,
+               "samples_with_colour_branch": n_col, "colour_branch_flop_per_sample": 294912, "algorithmic_flop_per_launch": flop_launch,
+               "colour_passes_skipped_fraction": 1.0 - n_col / max(n_eval, 1.0),
+               "achieved_counting_skipped_colour_branch": n_eval * 754176 / (ms_mlp * 1e-3) / 1e12,
                "avg_launch_ms": ms_mlp, "ray_hit_fraction": hit, "group_hit_fraction": ev["group_hit_fraction"],
                "early_termination_eps": eps, "passes_skipped_by_termination": ev["passes_skipped_by_termination"],
                "issued_over_algorithmic": issued, "issued_frac_of_peak": ach_m * issued / mfma_peak_tflops,
@@ -612,8 +622,9 @@ class Renderer:
                "note": ("the launch ALSO contains the encode stage of its samples (sample placement + 8-corner gathers of 16 levels, "
                         "the work of the former encode_kernel): its time is in the denominator, its bytes are not in the numerator; "
                         if field_kernel else "") +
-                       "achieved = samples evaluated x 754 176 FLOP / launch time (skipped sky groups are not counted as "
-                       "work); the kernel issues `issued_over_algorithmic` MFMA slots per algorithmic product (hi*hi + "
+                       "achieved = (samples evaluated x 459 264 FLOP of trunk + density head + samples whose pass ran the colour branch x "
+                       "294 912 FLOP) / launch time (skipped sky groups, terminated passes and skipped colour branches are not "
+                       "counted as work); the kernel issues `issued_over_algorithmic` MFMA slots per algorithmic product (hi*hi + "
                        "lo*hi + hi*lo: plain f16 misses the 1e-3 bound 17x; in the colour layers the two corrections run as "
                        "block-scaled fp6 at 4x the rate); traffic = HBM bytes per launch from the "
                        "PMC profile named in traffic_source (a separate rocprofv3 --pmc run, not this process)"}

@@ -79,6 +79,61 @@ def test_backend_tracks_live_parameters():
     assert len(calls) == 2 and torch.equal(calls[1], z)
 
 
+def test_backend_style_is_not_fooled_by_a_recycled_address():
+    """The reference builds z = style_net(style) afresh per call and frees the old one: the allocator hands the next z the same
+    address with version 0 again.  The backend keeps the keyed tensor alive, so "same address" can only mean "same storage"."""
+    import gc
+    from scenedreamer_amd import modules
+    B = modules.Backend()
+    calls = []
+    fold = lambda b, zz: calls.append(zz.clone())
+    z1 = torch.full((1, 256), 1.0)
+    p1 = z1.data_ptr()
+    B.style("render_net.", z1, 0, fold)
+    assert B._zref["render_net."] is z1
+    del z1
+    gc.collect()
+    z2 = torch.full((1, 256), 2.0)                 # would land on z1's address if z1 had been released
+    assert z2.data_ptr() != p1                     # ... it was not: the backend holds it
+    B.style("render_net.", z2, 0, fold)
+    assert len(calls) == 2 and float(calls[1][0, 0]) == 2.0
+    v = z2[0:1]                                    # a view of the folded tensor: same content, no refold
+    B.style("render_net.", v, 0, fold)
+    assert len(calls) == 2
+    # a rebind (new weights) forgets the style: the next call folds again
+    m = modules.SKYMLP(33, 256, 64)
+    B.bind("render_net.", m)
+    B.style("render_net.", z2, 0, fold)
+    assert len(calls) == 3
+
+
+def test_one_row_tiles_only_coalesce_when_the_frame_pitch_is_known(monkeypatch):
+    """frame_window cannot see the frame's row pitch in a one-row tile: rays() recovers it from the sky pre-pass's
+    ray directions or marks the window as not coalescible."""
+    from scenedreamer_amd import dropin, fused, modules
+    H0, W0, M = 7, 10, 6
+    vid = torch.zeros((1, H0, W0, M, 1), dtype=torch.int32)
+    d2 = torch.zeros((1, 2, H0, W0, M, 1))
+    rd = torch.zeros((1, H0, W0, 1, 3))
+    v, d, r = vid[:, 6:7, 4:9], d2[:, :, 6:7, 4:9], rd[:, 6:7, 4:9]
+    win, bases = dropin.GeneratorBinding.frame_window(v, d, r)
+    assert win.pitch == 5 and win.first == 6 * W0 + 4 and win.n_rays == 5       # pitch is a guess here
+
+    class Sky:
+        pass
+    b = dropin.GeneratorBinding()
+    b.B._zkey["sky_net."] = ("k",)
+    G = type("G", (), {})()
+    G.sky_net = Sky()
+    monkeypatch.setattr(modules.Backend, "tensors_key", staticmethod(lambda m: "w"))
+    Sky._sdn_native = True
+    for ref_shape, known in (((1, H0, W0, 1, 3), True), ((H0 * W0, 3), False)):
+        G.sky_net.__dict__["_sdn_last_frame"] = dict(rd_ref=rd.view(ref_shape), rd_ptr=rd.data_ptr(), rd_version=rd._version,
+                                                     n_rays=H0 * W0, sky_c="sky", zkey=("k",), wkey="w")
+        win, *_ = b.rays(G, v, d, r)
+        assert getattr(win, "pitch_known") is known and win.pitch == (W0 if known else 5)
+
+
 def test_composite_forwards_without_a_gpu():
     """CPU tensors (or autograd) go through the composite forward and say why."""
     from scenedreamer_amd import modules
@@ -167,6 +222,7 @@ def test_frame_image_tile_maps_tile_views_of_the_cached_frame():
     class _G:
         denoiser = None
     b._frame["img_key"] = ((z.data_ptr(), z._version), None)      # the image of this style is already there: no CNN call
+    b._frame["img_z"] = z                                          # (the keyed tensor is held, so its address stays its own)
     for hb, he, wb, we in ((0, 14, 0, 14), (8, 23, 16, 31), (3, 4, 5, 31), (0, 23, 30, 31)):
         tile = full[:, hb:he, wb:we, :]
         got = b.frame_image_tile(_G, tile, z)

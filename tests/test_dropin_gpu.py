@@ -91,6 +91,58 @@ def test_lightning_mlp_notices_new_weights_and_styles(nets):
     assert float((b[1] - rb[1]).abs().max()) < 2e-4 and float((c[1] - rc[1]).abs().max()) < 2e-4
 
 
+def test_a_new_style_tensor_on_a_recycled_address_is_folded_again(nets):
+    """the reference builds z = style_net(style) afresh per call and frees the old one; the caching allocator
+    hands the next z the same address with version counter 0.  The backends hold the tensor their fold was keyed on, so the new
+    style cannot be mistaken for it: all three networks render the NEW style, and one-hot-ness of `m` decides native vs
+    composite."""
+    mlp, sky, cnn = nets
+    x = (torch.rand((1, 5, 6, 4, 128), generator=torch.Generator().manual_seed(3)) - 0.5).cuda()
+    m = torch.zeros((1, 5, 6, 4, 12), device="cuda")
+    m[..., 7] = 1
+    rows = (torch.rand((1, 50, 33), generator=torch.Generator().manual_seed(4)) * 2 - 1).cuda()
+    img_in = (torch.rand((1, 64, 24, 40), generator=torch.Generator().manual_seed(5)) * 2 - 1).cuda()
+    outs = []
+    with torch.no_grad():
+        for seed in (0, 1):
+            z = _style_code(seed)                   # a fresh tensor per "call of the generator"
+            o = (mlp(x, None, z, m)[1], sky(rows, z), cnn(img_in, z))
+            r = (mlp._forward_composite(x, None, z, m)[1], sky._forward_composite(rows, z), cnn._forward_composite(img_in, z))
+            for a, b, tol in zip(o, r, (2e-4, 3e-4, 5e-3)):
+                assert float((a - b).abs().max()) < tol * max(1.0, float(b.abs().max())), seed
+            outs.append(o)
+            del z
+            torch.cuda.synchronize()
+        assert all(float((a - b).abs().max()) > 1e-3 for a, b in zip(*outs))     # the second style was rendered, not the first again
+        # soft labels are not what the label-bias shortcut computes: composite path, same answer as the reference arithmetic
+        z = _style_code(1)
+        soft = m * 0.9 + 0.1 / 12
+        assert mlp.native_reason(x, None, z, m) is None and mlp.native_reason(x, None, z, soft) == "m is not one-hot"
+        a, b = mlp(x, None, z, soft), mlp._forward_composite(x, None, z, soft)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_trunk_weights_beyond_f16_fall_back_instead_of_raising(nets):
+    """a style whose scaled trunk weights leave f16's range is served by the composite forward (the explicit
+    Renderer API still raises fused.TrunkRangeError)."""
+    from scenedreamer_amd import modules
+    mlp = nets[0]
+    mine = modules.LightningMLP(128, 256, 0, mask_dim=12, out_channels_s=1, out_channels_c=64)
+    mine.load_state_dict(mlp.state_dict())
+    mine = mine.cuda().eval()
+    for p in mine.parameters():
+        p.requires_grad_(False)
+    x = (torch.rand((1, 3, 4, 2, 128), generator=torch.Generator().manual_seed(3)) - 0.5).cuda()
+    m = torch.zeros((1, 3, 4, 2, 12), device="cuda")
+    m[..., 2] = 1
+    z = _style_code()
+    with torch.no_grad():
+        mine.fc_1.weight.mul_(2000.0)               # |w| * 2^8 beyond 32768
+        a = mine(x, None, z, m)
+        b = mine._forward_composite(x, None, z, m)
+    assert "f16" in mine.__dict__.get("_sdn_composite_reason", "") and torch.equal(a[1], b[1])
+
+
 def test_sky_mlp_module_encoded_rows_and_tagged_directions(nets):
     """SKYMLP.forward (gancraft_base.py:150-169): (a) any [.., 33] rows -> sky_kernel<PRE>; (b) the output of this package's
     voxlib.positional_encoding -> the kernel encodes the ray directions itself; (c) an in-place edit of that tensor voids the tag."""

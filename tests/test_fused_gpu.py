@@ -450,6 +450,43 @@ def test_single_kernel_field_equals_the_two_kernel_field(renderer):
             renderer.set_precision()
 
 
+def test_colour_branch_skipping_is_bit_exact(renderer):
+    """field_kernel leaves out fc_5 / fc_6 / fc_out_c in passes whose 128 samples all have relu(sigma) * dist == 0 (weights
+    exactly zero, mc_utils.py:154-161): net_out must not change by one bit against the launch that evaluates every pass --
+    whole ray set, cropped window, both precision profiles, with and without early termination -- and the skipped passes are
+    counted (colour_passes <= passes, equal where nothing was skipped)."""
+    from scenedreamer_amd import fused
+    pose, vid, d2, rd, H0, W0 = _frame(renderer)
+    ori = torch.as_tensor(pose[0], dtype=torch.float32)
+    n = vid.shape[0]
+    ng = (n + 31) // 32
+    with torch.no_grad():
+        sky_c, sky_avg = fused.sky_fused(renderer, rd)
+        win = fused.Window.crop(H0, W0, 7)
+        try:
+            renderer.field_single_kernel = True
+            for ct, eps in ((6, 0.0), (3, 0.0), (6, 5e-5), (6, 0.2)):
+                renderer.set_precision(colour_terms=ct, term_eps=eps)
+                outs = {}
+                for skip in (False, True):
+                    renderer.colour_skip = skip
+                    pa, cp = torch.zeros(ng, dtype=torch.uint8, device="cuda"), torch.full((ng,), 255, dtype=torch.uint8, device="cuda")
+                    a = fused.field_render(renderer, vid, d2, rd, ori, sky_c, sky_avg, 24, passes=pa, colour_passes=cp)
+                    b = fused.field_render(renderer, vid, d2, rd, ori, sky_c, sky_avg, 24, window=win)
+                    outs[skip] = (a, b, pa, cp)
+                assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1]), (ct, eps)
+                assert torch.equal(outs[False][2], outs[True][2])                       # the same passes were gone through
+                assert torch.equal(outs[False][3], outs[False][2])                      # no skipping: every pass ran the colour branch
+                assert bool((outs[True][3] <= outs[True][2]).all())
+                ran, went = int(outs[True][3].sum(dtype=torch.int64)), int(outs[True][2].sum(dtype=torch.int64))
+                print(f"colour_terms {ct}, term_eps {eps}: colour branch evaluated in {ran} of {went} passes ({100 * (1 - ran / max(went, 1)):.1f} % skipped)")
+                assert 0 < ran < went                                                     # the synthetic field does have empty space
+        finally:
+            renderer.field_single_kernel = None
+            renderer.colour_skip = None
+            renderer.set_precision()
+
+
 def test_early_termination_single_kernel_equals_two_kernel(renderer):
     """term_eps > 0 (wavefront-ballot early ray termination): the single-kernel field finishes `is_gnd` over the passes it
     skips (placement only), so it still chooses the same sky term as encode_kernel -> mlp_kernel, which knows all samples up

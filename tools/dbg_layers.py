@@ -33,9 +33,11 @@ for pi in (0,):
         for _ in range(2):
             out = fused.field_fused(R, vid, d2, rd, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, 24)
         torch.cuda.synchronize()
-        t = out.view(-1, 64)[0:1024:4, 3:14].double().cpu()          # one row per workgroup
+        t = out.view(-1, 64)[0:1024:4, 3:16].double().cpu()          # one row per workgroup
     passes = t[:, 10].sum()
-    tot = t[:, :10].sum()
+    tot = t[:, :10].sum() + t[:, 11].sum()
+    print(f"  colour branch skipped in {int(t[:, 12].sum())} of {int(passes)} passes; the decision (early sigma + ballot) costs "
+          f"{t[:, 11].sum() / passes:.0f} cycles per pass")
     print(f"pose {pi}: {int(passes)} passes of {t.shape[0]} workgroups, {tot / passes:.0f} cycles per pass (thread 0 of each workgroup)")
     for k, nm in enumerate(names):
         c = t[:, k].sum() / passes

@@ -329,6 +329,26 @@ int main(int argc, char **argv) {
         hipMemcpy(w, h.data(), h.size() * 2, hipMemcpyHostToDevice);
         hipMemcpy(in, h.data(), 64 * 32 * 16, hipMemcpyHostToDevice);
     }
+    if (argc > 1 && std::string(argv[1]) == "--zero-cols") {
+        // Does the MATRIX PIPE's power depend on the operand data per sample?  B fragments (activations) of a fraction of the 32
+        // samples (columns) of every wave are all-zero; the variants without activation stages keep B as loaded.  If a zeroed
+        // column costs visibly less wall time under the power limit, samples whose result is provably unused (relu(sigma) == 0:
+        // volume-rendering weight exactly 0, mc_utils.py:154-161) can be run through the colour layers as zeros.
+        std::vector<unsigned short> h(64 * 32 * 8);
+        for (int zc = 0; zc <= 32; zc += 8) {
+            unsigned x = 777u;
+            for (size_t i = 0; i < h.size(); i++) {
+                x = x * 1664525u + 1013904223u;
+                const int lane = (int)((i / 8) % 64);
+                h[i] = (lane & 31) < zc ? (unsigned short)0 : (unsigned short)(0x3000u | ((x >> 16) & 0x0fffu) | ((x >> 3) & 0x8000u));
+            }
+            hipMemcpy(in, h.data(), 64 * 32 * 16, hipMemcpyHostToDevice);
+            printf("== %d of 32 sample columns zero\n", zc);
+            run("A no activation (DMA ring + MFMA)", shapeA<4>, 256, out, in, w);
+            run("A MFMA + fragment reads only", shapeA<7>, 256, out, in, w);
+        }
+        return 0;
+    }
     if (ceiling) {
         auto tf = [](double us) { return 128.0 * 2 * 256 * 256 * 256 / us * 1e-6; };   // algorithmic TFLOP/s on 256 CUs (product counted once)
         run("A MFMA + fragment reads only", shapeA<7>, 256, out, in, w);
