@@ -231,7 +231,7 @@ def _reference_tiles(weights, scene, vox, pose, hw, ns, z, genc, picks, pad=30, 
     return t_frame, t_tiles, got
 
 
-def dropin_record(args, weights, scene, dev):
+def dropin_record(args, weights, scene, dev, oracle_tiles=None):
     """The UNMODIFIED reference generator -- imaginaire.generators.scenedreamer.Generator.inference_givenstyle, its own frame loop
     (scenedreamer.py:479-632) -- on `scenedreamer_amd.install_shims(fast=True)`: voxlib / gridencoder served by the HIP ops, its
     LightningMLP / SKYMLP / RenderCNN classes and its _forward_perpix / _forward_global methods bound to the fused kernels from
@@ -307,6 +307,26 @@ def dropin_record(args, weights, scene, dev):
                                          "tile_size >= frame -- an argument of the unmodified method: one _forward_perpix / "
                                          "_forward_global call per frame"),
                                 "calls": {k: v - before[k] for k, v in b.stats.items() if k != "why"}, "reference_path_reasons": dict(b.stats["why"])})
+        if oracle_tiles:
+            # the loop's OWN pixels (float, before its uint8 conversion) of the pose the CPU baseline rendered -- frame 8 of the 40-step
+            # orbit, default tiling, the frame evaluated once for its 40 tiles -- against those CPU tiles
+            b = dropin.binding(G)
+            b.coalesce = True
+            got = []
+            b.on_frame = lambda fr: got.append(fr["img"].clone() if len(got) == 8 else None)
+            try:
+                G.inference_givenstyle(style, os.path.join(tmp, "err"), cam_maxstep=40, camera_mode=0, num_samples=args.samples, tile_size=128,
+                                       resolution_hw=hw, cam_ang=72)
+            finally:
+                b.on_frame = None
+            if len(got) == 40 and got[8] is not None:
+                c = (got[8].shape[2] - hw[0]) // 2
+                img = got[8][:, :, c:c + hw[0], c:c + hw[1]].cpu().numpy()
+                errs = [float(np.abs(img[:, :, r0:r0 + im.shape[2], c0:c0 + im.shape[3]] - im.numpy()).max()) for r0, c0, im in oracle_tiles.values()]
+                out["max_abs_err"] = max(errs)
+                out["max_abs_err_where"] = (f"{len(errs)} tiles of the reference's tile grid, frame 8 of the 40-step orbit rendered by the unmodified loop "
+                                            "(tile_size 128, frame evaluated once), float image before the loop's uint8 conversion, vs the fp32 CPU "
+                                            "run of cpu_baseline; bound 1e-3")
     out["cnn_gate"] = b.B.cnn_calibration
     del G
     torch.cuda.empty_cache()
@@ -667,7 +687,7 @@ def main():
         R.render_frame(frame_pose(args.warmup + k), hw, args.samples, mode=mode, apron=other)
     torch.cuda.synchronize()
     other_ms = 1000.0 * (time.perf_counter() - t1) / n_other if n_other else None
-    roof_cnn = None
+    roof_cnn = roof_sky = None
     if tile_parallel:     # per-kernel records on this rank's band (every rank does 1/N of the frame)
         roof, roof_grid = None, None
     elif probe.get("mlp_kernel"):
@@ -708,6 +728,38 @@ def main():
                     "alone_ms": stage_ms.get("cnn"),
                     "frac_alone": (px * 5015040 / (stage_ms["cnn"] * 1e-3) / 1e12 / 2500.0) if stage_ms.get("cnn") else None,
                     "timing": "HIP events around the CNN of every timed frame on the main stream"}
+        # ---- per-launch records of the kernels the three records above do not break down: the render CNN's six launches and the
+        #      sky MLP, each ALONE on the GPU (5 repetitions on the evaluated frame, outside the timed region)
+        try:
+            Hc, Wc = (hw[0] + 8, hw[1] + 8) if args.apron == "minimal" else (hw[0] + 30, hw[1] + 30)
+            xin = torch.rand(1, Hc, Wc, 64, device=dev) * 2 - 1
+            cnn = R.mfma_cnn(xin)
+            cnn(xin)
+            tm = {}
+            for _ in range(5):
+                cnn(xin, timers=tm)
+            torch.cuda.synchronize()
+            per = {}
+            for name, fl in cnn.FLOP_PER_PIXEL.items():
+                ms_k = float(np.mean([a.elapsed_time(b) for a, b in tm[name]]))
+                t_k = cnn.terms.get(name.split(" ")[0], 3)
+                per[name] = {"avg_launch_ms": ms_k, "algorithmic_flop_per_pixel": fl, "achieved": Hc * Wc * fl / (ms_k * 1e-3) / 1e12,
+                             "frac": Hc * Wc * fl / (ms_k * 1e-3) / 1e12 / 2500.0, "f16_products_per_algorithmic_product": t_k}
+            roof_cnn["per_launch_alone"] = {"pixels": Hc * Wc, "unit": "TFLOP/s", "peak": 2500.0, "bound": "mfma", "kernels": per,
+                                            "timing": "HIP events between the launches, 5 repetitions, nothing else on the GPU"}
+            n_sky = (hw[0] + 30) * (hw[1] + 30)
+            from scenedreamer_amd import fused as _fused
+            from scenedreamer_amd.renderer import _time_ms
+            rd_sky = torch.nn.functional.normalize(torch.randn(n_sky, 3, device=dev), dim=-1)
+            ms_sky = _time_ms(lambda: _fused.sky_fused(R, rd_sky), 5)
+            roof_sky = {"bound": "mfma", "kernel": f"sky_kernel (SKYMLP on every ray of the padded frame + the frame mean; hidden layers "
+                                                   f"{'f16 + MX-fp6 corrections' if _fused.sky_terms(R) == 6 else '3-term f16'})",
+                        "rays": n_sky, "algorithmic_flop_per_ray": 573952, "avg_launch_ms": ms_sky,
+                        "achieved": n_sky * 573952 / (ms_sky * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                        "frac": n_sky * 573952 / (ms_sky * 1e-3) / 1e12 / 2500.0,
+                        "timing": "5 stand-alone launches, nothing else on the GPU (in the timed region it runs beside the previous frame's CNN)"}
+        except Exception as ex:  # noqa: BLE001 -- extra records must not cost the headline line
+            roof_sky = {"error": f"{type(ex).__name__}: {ex}"}
         if one_kernel:   # the MLP stage by itself (mlp_kernel on pre-encoded features: the same layers without the encode stage)
             roof["mlp_stage_alone"] = {"kernel": "mlp_kernel (stand-alone launches on pre-encoded features, outside the timed region)",
                                        "avg_launch_ms": alone[0]["avg_launch_ms"], "achieved": alone[0]["achieved"],
@@ -764,6 +816,7 @@ def main():
             "frame_ms_p10_p50_p90": [pct(0.1), pct(0.5), pct(0.9)], "delivered_frames_per_s_uint8_host": delivered_fps,
             "stage_ms": stage_ms, "setup_s": setup_s, "broadcast": bstats or None, f"ms_per_step_apron_{other}": other_ms,
             "roofline": roof, "roofline_grid_sampler": roof_grid, "roofline_cnn": roof_cnn, "roofline_rvip": roof_rvip,
+            "roofline_sky": roof_sky,
             "early_termination": early,
         }
         gates = {"cnn": getattr(R, "cnn_calibration", None),
@@ -793,6 +846,31 @@ def main():
         if "precision" not in out:
             out["precision"] = {"gates": gates, "max_abs_err": None,
                                 "note": "per-style gates only: the error against the CPU run is measured with the cpu_baseline leg"}
+        if world == 1 and mode == "fused" and not tile_parallel and not args.no_extras:
+            # north star: "within 1e-3 vs the reference CUDA path".  Its nearest stand-in on this box: the reference's op sequence
+            # in fp32 on the GPU -- sample placement by PyTorch ops on a GPU tensor (mc_utils.py:82-151: torch.cumsum accumulates
+            # in float32 there, in double on the CPU the oracle follows), this package's drop-in grid op, torch fp32 MLP / conv2d.
+            # One whole frame, reference apron, outside the timed region.
+            try:
+                pz = frame_pose(args.warmup)
+                a = R.render_frame(pz, hw, args.samples, mode="fused", apron=args.apron)
+                b = R.render_frame(pz, hw, args.samples, mode="unfused", cnn_mode="torch")
+                torch.cuda.synchronize()
+                t_fb = time.perf_counter()
+                for _ in range(2):
+                    R.render_frame(pz, hw, args.samples, mode="unfused", cnn_mode="torch")
+                torch.cuda.synchronize()
+                # what a style pays when calibrate_style rejects the MFMA path (gain-scaled weights in tests/test_precision_gates_gpu.py):
+                # the fp32 op sequence below the HIP ray marcher / grid op is PyTorch (rocBLAS addmm, MIOpen conv2d), not a HIP rung
+                out["fallback_fp32_path_frames_per_s"] = 2.0 / (time.perf_counter() - t_fb)
+                e = (a - b).abs()
+                out["precision"]["vs_gpu_placement_fp32_path"] = {
+                    "max_abs_diff": float(e.max()), "fraction_above_1e-4": float((e > 1e-4).float().mean()), "pixels": int(e[0, 0].numel()),
+                    "what": "fused HIP frame vs Renderer.render_frame(mode='unfused', cnn_mode='torch'): torch-op sample placement on the GPU "
+                            "(float32 cumsum, as the reference's CUDA path places samples), HIP grid op, fp32 torch MLP and convolutions; "
+                            "also asserted < 1e-3 at 960x540 and 1920x1080 in tests/test_fullsize_gpu.py"}
+            except Exception as ex:  # noqa: BLE001 -- an extra record must not cost the headline line
+                out["precision"]["vs_gpu_placement_fp32_path"] = {"error": f"{type(ex).__name__}: {ex}"}
         if world == 1 and mode == "fused" and not tile_parallel:
             if not args.no_other_configs and (hw, args.samples, args.scene_size) == ((540, 960), 24, 2048):
                 try:
@@ -803,7 +881,7 @@ def main():
                 del R
                 torch.cuda.empty_cache()
                 try:
-                    out["dropin"] = dropin_record(args, weights, scene, dev)
+                    out["dropin"] = dropin_record(args, weights, scene, dev, getattr(cpu_baseline, "tiles", None))
                 except Exception as e:  # noqa: BLE001
                     out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))

@@ -10,7 +10,10 @@ Precision profile (`terms3x3`): the 1x1 layers always use the 3-term f16 split; 
 3-term split (< 2e-5 from the fp32 CNN) or ONE term (Whi.Xhi, both rounded to nearest: a third of the MFMAs; measured
 image error vs the fp32 CNN ~7e-5 rms / < 5e-4 max on the synthetic weights, tools/precision_study.py).  The 1-term form
 is lossy in a weight-dependent way, so which one runs is decided per style by Renderer.mfma_cnn (a measured gate), not
-here; this class takes the decision as `terms3x3`."""
+here; this class takes the decision as `terms3x3`: 1, 3, or one choice per layer (conv2a, conv2b, conv3a, conv3b) as a 4-tuple or
+a string like "1113" -- the rungs between "all one product" and "all 3-term" (CNN_LADDER: the LAST 3x3 layers go 3-term first:
+on the synthetic weights conv3b alone takes 20 - 30 % off the 1-term error for +0.6 ms, profiles/r05_cnn_ladder_study.txt; a
+2-term split of all four layers costs twice that and corrects the weights only -- the activations' rounding is what matters)."""
 import ctypes
 import os
 
@@ -20,16 +23,40 @@ from . import capi
 
 _LAYERS = {"conv1": (64, 1), "conv2a": (256, 9), "conv2b": (256, 9), "conv3a": (256, 9), "conv3b": (256, 9),
            "conv4a": (256, 1), "conv4b": (256, 1)}
+_3X3 = ("conv2a", "conv2b", "conv3a", "conv3b")
+CNN_LADDER = (1, "1113", "1133", 3)       # cheapest first: 4, 6, 8, 12 one-product layer equivalents
+
+
+def form_key(terms3x3):
+    """Canonical name of a 3x3 precision form: 1, 3 (all four layers alike) or a 4-character string of 1 / 3."""
+    if isinstance(terms3x3, (tuple, list)):
+        terms3x3 = "".join(str(int(t)) for t in terms3x3)
+    if isinstance(terms3x3, str):
+        assert len(terms3x3) == 4 and set(terms3x3) <= {"1", "3"}, terms3x3
+        return 1 if terms3x3 == "1111" else 3 if terms3x3 == "3333" else terms3x3
+    assert int(terms3x3) in (1, 3), terms3x3
+    return int(terms3x3)
+
+
+def form_terms(terms3x3):
+    """(conv2a, conv2b, conv3a, conv3b) product terms of a form."""
+    k = form_key(terms3x3)
+    return (k,) * 4 if isinstance(k, int) else tuple(int(c) for c in k)
+
+
+def form_cost(terms3x3):
+    return sum(form_terms(terms3x3))
 
 
 class MfmaCNN:
     def __init__(self, R, terms3x3, chain=None):
         self.R = R
-        assert terms3x3 in (1, 3)
+        self.form = form_key(terms3x3)
+        per3x3 = dict(zip(_3X3, form_terms(terms3x3)))
         if chain is None:
             chain = os.environ.get("SDN_CNN_CHAIN", "1") != "0"
         self.chain = bool(chain)
-        self.terms = {n: (terms3x3 if taps == 9 else 3) for n, (_, taps) in _LAYERS.items()}
+        self.terms = {n: per3x3.get(n, 3) for n in _LAYERS}
         lib = capi.lib()
         w = R.w
         self.packed = {}
@@ -98,9 +125,23 @@ class MfmaCNN:
                                            p(proj[0]) if proj else None, p(proj[1]) if proj else None, p(img),
                                            H, W, 0, capi.current_stream(self.R.dev)), "sdn_conv")
 
-    def __call__(self, net_out, raw=None):
+    FLOP_PER_PIXEL = {"head (conv1)": 2 * 64 * 256, "conv2a": 2 * 9 * 256 * 256, "conv2b": 2 * 9 * 256 * 256, "conv3a": 2 * 9 * 256 * 256,
+                      "conv3b": 2 * 9 * 256 * 256, "chain (conv4a, conv4b, conv4)": 2 * (2 * 256 * 256 + 256 * 3)}    # sums to 5 015 040
+
+    def __call__(self, net_out, raw=None, timers=None):
         """net_out [1,H,W,64] -> image [1,3,H,W] (tanh).  raw: optional f32 [1,3,H,W] that receives conv4's output before the
-        tanh (RenderCNN.forward's own return value, gancraft_base.py:221-225; needs the chained tail)."""
+        tanh (RenderCNN.forward's own return value, gancraft_base.py:221-225; needs the chained tail).
+        timers: optional dict; receives (start, end) event pairs per launch, keyed like FLOP_PER_PIXEL (bench.py's per-kernel records)."""
+        last = [None]
+
+        def tick(name=None):
+            if timers is None:
+                return
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            if name is not None:
+                timers.setdefault(name, []).append((last[0], e))
+            last[0] = e
         if raw is not None and not self.chain:
             raise ValueError("the pre-tanh output is produced by the chained tail (chain=True)")
         R, w = self.R, self.R.w
@@ -113,6 +154,7 @@ class MfmaCNN:
         img = torch.empty(1, 3, H, W, device=R.dev)
         # the running activation y lives in planes A (hi + lo f16 = y to 2^-22) and is updated in place by the
         # residual convolutions; planes B hold the inner activation of each residual block
+        tick()
         if self.chain:                                                                             # y = act(conv1(x))
             with torch.cuda.device(R.dev):
                 capi.check(capi.lib().sdn_conv_head(x.data_ptr(), self.head_packed.data_ptr(), self.head_bias.data_ptr(),
@@ -123,18 +165,24 @@ class MfmaCNN:
                 capi.check(capi.lib().sdn_conv_planes_from_f32(x.data_ptr(), 64, B[0].data_ptr(), B[1].data_ptr(), H, W,
                                                                capi.current_stream(R.dev)), "sdn_conv_planes_from_f32")
             self._conv(B, "conv1", H, W, bias=bias("conv1"), dst=A)
-        # the inner activations are consumed only by conv2b / conv3b: no lo plane when those are 1-term
-        inner = (B[0], None) if self.terms["conv2b"] == 1 else B
-        self._conv(A, "conv2a", H, W, bias=bias("conv2a"), dst=inner)                              # act(conv2a(y))
+        # the inner activations are consumed only by conv2b / conv3b: no lo plane when that layer is 1-term
+        inner = lambda consumer: (B[0], None) if self.terms[consumer] == 1 else B
+        tick("head (conv1)")
+        self._conv(A, "conv2a", H, W, bias=bias("conv2a"), dst=inner("conv2b"))                    # act(conv2a(y))
+        tick("conv2a")
         self._conv(B, "conv2b", H, W, bias=bias("conv2b"), resid_planes=A, mod=(a[0], a[1]), dst=A)
-        self._conv(A, "conv3a", H, W, bias=bias("conv3a"), dst=inner)
+        tick("conv2b")
+        self._conv(A, "conv3a", H, W, bias=bias("conv3a"), dst=inner("conv3b"))
+        tick("conv3a")
         self._conv(B, "conv3b", H, W, bias=bias("conv3b"), resid_planes=A, mod=(a[2], a[3]), dst=A)
+        tick("conv3b")
         if self.chain:
             with torch.cuda.device(R.dev):
                 capi.check(capi.lib().sdn_conv_chain(A[0].data_ptr(), A[1].data_ptr(), self.chain_packed.data_ptr(),
                                                      self.chain_consts.data_ptr(), img.data_ptr(),
                                                      raw.data_ptr() if raw is not None else None, H, W, 0,
                                                      capi.current_stream(R.dev)), "sdn_conv_chain")
+            tick("chain (conv4a, conv4b, conv4)")
             return img
         self._conv(A, "conv4a", H, W, bias=bias("conv4a"), dst=B)
         self._conv(B, "conv4b", H, W, bias=bias("conv4b"), resid_planes=A, proj=(self.w4, self.b4), img=img)

@@ -312,8 +312,8 @@ def agree_precision(renderer, pose, resolution_hw, num_samples, group=None):
     meas = renderer.calibrate_style(pose, resolution_hw, num_samples)["measurements"]
     if _is_init() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
-        slots = [("field_err", k) for k in sorted(meas["field_err"])] + [("image_err", k) for k in sorted(meas["image_err"])]
-        slots += [("sky_err", k) for k in sorted(meas.get("sky_err", {}))] + [(k, None) for k in ("colour_diff", "cnn_diff") if k in meas]
+        slots = [(a, k) for a in ("field_err", "image_err", "sky_err", "cnn_diffs") for k in sorted(meas.get(a) or {}, key=str)]
+        slots += [(k, None) for k in ("colour_diff", "cnn_diff") if k in meas]
         v = torch.tensor([meas[a][b] if b is not None else meas[a] for a, b in slots], dtype=torch.float64, device=renderer.dev)
         all_reduce(v, op=dist.ReduceOp.MAX, group=group)
         for (a, b), x in zip(slots, v.tolist()):

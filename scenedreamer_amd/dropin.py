@@ -58,6 +58,8 @@ class GeneratorBinding:
         self._frame = None          # the frame evaluated once for all of its tiles (frame_field)
         self.coalesce = True
         self._refused = None        # (style key, message): prepare_style refused this style (TrunkRangeError) -- not retried per tile
+        self.on_frame = None        # optional callback(frame record) when a coalesced frame's image has been produced (tests / bench:
+                                    # record["img"] is the float image [1,3,H0,W0] of the padded frame the loop's tiles are views of)
 
     def release(self, G=None):
         """Drop the frame-sized device buffers this binding pins between calls (net_out / image of the last coalesced frame
@@ -273,6 +275,8 @@ class GeneratorBinding:
             fr["raw"] = raw
             fr["img_key"] = (zkey, B._bound["denoiser."][1])
             fr["img_z"] = z
+            if self.on_frame is not None:
+                self.on_frame(fr)
         self.stats["cnn_tiles_from_frame"] += 1
         return fr["img"][:, :, hb:hb + h, wb:wb + w], fr["raw"][:, :, hb:hb + h, wb:wb + w]
 

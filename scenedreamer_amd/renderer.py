@@ -270,8 +270,8 @@ class Renderer:
     # ------------------------------------------------------------------ measurement
     def set_precision(self, cnn_terms3x3=None, colour_terms=None, term_eps=None):
         """Precision profile of the MFMA kernels (None = the default of the environment / library):
-        cnn_terms3x3: f16 product terms of the four 3x3 convolutions: 1, 3, or None = "auto" (1 if it passes the per-style
-                      calibration against the 3-term evaluation, else 3 -- see mfma_cnn);
+        cnn_terms3x3: f16 product terms of the four 3x3 convolutions: 1, 3, a per-layer form like "1113" (cnn.CNN_LADDER), or
+                      None = "auto" (the cheapest rung of the ladder that passes the per-style calibration -- see mfma_cnn);
         colour_terms: products of the colour layers fc_5 / fc_6: 6 (default: f16 + fp6 corrections), 3 or 2 (fused.precision_profile);
         term_eps: early ray termination threshold on the transmittance, 0 = off (default)."""
         self.cnn_terms3x3, self.colour_terms, self.term_eps = cnn_terms3x3, colour_terms, term_eps
@@ -293,9 +293,10 @@ class Renderer:
             3-term evaluation, else the 3-term split;
           the fused field (3-term f16 split, f32 accumulate): net_out against the fp32 net_out, bound FIELD_AUTO_BOUND -- above
             it the style is served by the fp32 op sequence (`path: "unfused"`): slow, but inside the tolerance;
-          render CNN 3x3 layers: ONE f16 product if the image stays within CNN_AUTO_BOUND of the 3-term image AND its MEASURED
-            total error against the fp32 image (field error included) within IMAGE_AUTO_BOUND; else the 3-term split if THAT is
-            within IMAGE_AUTO_BOUND; else the fp32 path.
+          render CNN 3x3 layers: the cheapest rung of cnn.CNN_LADDER -- all four layers ONE f16 product; conv3b 3-term ("1113");
+            conv3a + conv3b 3-term ("1133"); all 3-term -- whose image stays within CNN_AUTO_BOUND of the 3-term image AND whose
+            MEASURED total error against the fp32 image (field error included) stays within IMAGE_AUTO_BOUND; if not even the
+            3-term image is within IMAGE_AUTO_BOUND, the fp32 path.
 
         The errors depend on the loaded weights (the density head amplifies hidden-activation error; 3x3 gains compound over
         four layers): tests/test_precision_gates_gpu.py scales them until every gate closes.  Explicit settings (set_precision,
@@ -355,10 +356,16 @@ class Renderer:
             if explicit_t is None and "SDN_CNN_TERMS" in os.environ:
                 explicit_t = int(os.environ["SDN_CNN_TERMS"])
             x = no[ct].view(1, H0, W0, 64)
-            imgs = {t: inner(self._cnn_form(t)(x)).clone() for t in ((explicit_t,) if explicit_t is not None else (1, 3))}
+            from .cnn import CNN_LADDER, form_key
+            if explicit_t is not None:
+                explicit_t = form_key(explicit_t)
+            # (every rung is measured, whichever is adopted: adopt_precision must be a function of `meas` alone, so that the ranks of
+            #  a multi-GPU job can reduce the measurements and reach the same decision)
+            imgs = {t: inner(self._cnn_form(t)(x)).clone() for t in ((explicit_t,) if explicit_t is not None else CNN_LADDER)}
             meas["image_err"] = {t: float((im - ref_img).abs().max()) for t, im in imgs.items()}
             if explicit_t is None:
-                meas["cnn_diff"] = float((imgs[1] - imgs[3]).abs().max())
+                meas["cnn_diffs"] = {t: float((imgs[t] - imgs[3]).abs().max()) for t in CNN_LADDER if t != 3}
+                meas["cnn_diff"] = meas["cnn_diffs"][1]
         meas.update(explicit_colour=explicit_ct, explicit_cnn=explicit_t, pixels=int(H * W), rays=int(n), samples_per_ray=int(num_samples),
                     frame=f"{W}x{H} (+{self.pad}-px apron), {num_samples} samples/ray")
         return self.adopt_precision(meas)
@@ -374,14 +381,19 @@ class Renderer:
         ierr = meas["image_err"]
         cal = None
         if et is None:
-            if meas["cnn_diff"] <= bound and ierr[1] <= IMAGE_AUTO_BOUND:
-                t = 1
-            else:
-                t = 3
-                if ierr[3] > IMAGE_AUTO_BOUND:
-                    path = "unfused"
+            from .cnn import CNN_LADDER
+            diffs = dict(meas.get("cnn_diffs") or {1: meas["cnn_diff"]})
+            t = 3
+            for cand in CNN_LADDER:         # cheapest first
+                if cand != 3 and cand in diffs and cand in ierr and diffs[cand] <= bound and ierr[cand] <= IMAGE_AUTO_BOUND:
+                    t = cand
+                    break
+            if t == 3 and ierr[3] > IMAGE_AUTO_BOUND:
+                path = "unfused"
             cal = {"terms3x3": t, "max_abs_diff_1term_vs_3term": meas["cnn_diff"], "bound": bound,
-                   "image_err_vs_fp32": {"1-term": ierr[1], "3-term": ierr[3]}, "image_bound": IMAGE_AUTO_BOUND,
+                   "max_abs_diff_vs_3term": {str(k): v for k, v in diffs.items()},
+                   "image_err_vs_fp32": {("1-term" if k == 1 else "3-term" if k == 3 else str(k)): v for k, v in ierr.items()},
+                   "image_bound": IMAGE_AUTO_BOUND, "ladder": [str(k) for k in CNN_LADDER],
                    "pixels": max(meas["pixels"], CNN_CAL_PIXELS), "calls": 1, "frame": meas["frame"], "measured": "end to end (calibrate_style)"}
         self.field_gate = {
             "path": path, "max_abs_err_vs_fp32": ferr, "bound": FIELD_AUTO_BOUND, "quantity": "net_out (per-ray feature, range [-1, 1])",
@@ -396,18 +408,23 @@ class Renderer:
             self.sky_terms_auto = 6 if (meas.get("explicit_sky") is None and meas["sky_err"].get(6, 1.0) <= SKY_AUTO_BOUND) else None
         if cal is not None:
             self.cnn_calibration = cal
-            cache = self.__dict__.setdefault("_mfma_cnns", {})
-            if (4 - cal["terms3x3"]) in cache:
-                cache[4 - cal["terms3x3"]]._planes.clear()      # the form not chosen keeps its packed weights, not its planes
+            self._drop_other_cnn_planes(cal["terms3x3"])
         return self.field_gate
+
+    def _drop_other_cnn_planes(self, keep):
+        """The forms not chosen keep their packed weights (9 MB each), not their activation planes (1.2 GB at 960x540)."""
+        for k, c in self.__dict__.get("_mfma_cnns", {}).items():
+            if k != keep:
+                c._planes.clear()
 
     def field_falls_back(self):
         g = getattr(self, "field_gate", None)
         return bool(g) and g.get("path") == "unfused"
 
     def _cnn_form(self, terms3x3):
-        from .cnn import MfmaCNN
+        from .cnn import MfmaCNN, form_key
         cache = self.__dict__.setdefault("_mfma_cnns", {})
+        terms3x3 = form_key(terms3x3)
         if terms3x3 not in cache:
             cache[terms3x3] = MfmaCNN(self, terms3x3)
         return cache[terms3x3]
@@ -436,27 +453,34 @@ class Renderer:
         if want is not None:
             return get(want)
         cal = getattr(self, "cnn_calibration", None)
-        if cal is None or (cal["terms3x3"] == 1 and cal["pixels"] < CNN_CAL_PIXELS):
+        if cal is None or (cal["terms3x3"] != 3 and cal["pixels"] < CNN_CAL_PIXELS):
             # calibration window: every net_out presented until CNN_CAL_PIXELS pixels of the style have been seen (one 960x540
-            # frame; the first ~20 tiles of the reference's tiled loop) goes through BOTH forms.  The 1-term image is used only
-            # while every comparison so far stayed inside the bound AND inside the image budget left by the field's own
-            # measured error (field_gate); the first violation closes the gate for the style.
+            # frame; the first ~20 tiles of the reference's tiled loop) goes through the 3-term form AND every cheaper rung of
+            # cnn.CNN_LADDER that has not failed yet.  The cheapest rung is used whose every comparison so far stayed inside the
+            # bound AND inside the image budget left by the field's own measured error (field_gate); a rung that violates either
+            # once is out for the style.
+            from .cnn import CNN_LADDER
             bound = float(getattr(self, "cnn_auto_bound", None) or CNN_AUTO_BOUND)
             fg = getattr(self, "field_gate", None)
             field_err = float(fg["max_abs_err_vs_fp32"]) if fg else FIELD_NOMINAL_ERR
+            worst = dict(cal["max_abs_diff_vs_3term"]) if cal else {}
+            fits = lambda v: v <= bound and field_err + v <= IMAGE_BUDGET
             with torch.no_grad():
-                d = float((get(3)(net_out) - get(1)(net_out)).abs().max())
+                ref3 = get(3)(net_out)
+                for cand in CNN_LADDER:
+                    if cand != 3 and fits(worst.get(str(cand), 0.0)):
+                        worst[str(cand)] = max(worst.get(str(cand), 0.0), float((ref3 - get(cand)(net_out)).abs().max()))
+            t = next((cand for cand in CNN_LADDER if cand != 3 and fits(worst[str(cand)])), 3)
             px = int(net_out.shape[1] * net_out.shape[2])
-            worst = max(d, cal["max_abs_diff_1term_vs_3term"]) if cal else d
-            ok = worst <= bound and field_err + worst <= IMAGE_BUDGET
             cal = self.cnn_calibration = {
-                "terms3x3": 1 if ok else 3, "max_abs_diff_1term_vs_3term": worst, "bound": bound,
+                "terms3x3": t, "max_abs_diff_1term_vs_3term": worst["1"], "max_abs_diff_vs_3term": worst, "bound": bound,
+                "ladder": [str(k) for k in CNN_LADDER],
                 "field_err_charged": field_err, "image_budget": IMAGE_BUDGET, "pixels": (cal["pixels"] if cal else 0) + px,
                 "calls": (cal["calls"] if cal else 0) + 1,
                 "frame": f"first {(cal['calls'] if cal else 0) + 1} net_out(s) of the style, {(cal['pixels'] if cal else 0) + px} px "
                          f"(window {CNN_CAL_PIXELS} px)"}
-            if not ok or cal["pixels"] >= CNN_CAL_PIXELS:
-                cache[4 - cal["terms3x3"]]._planes.clear()      # the form not chosen keeps its packed weights, not its planes
+            if t == 3 or cal["pixels"] >= CNN_CAL_PIXELS:
+                self._drop_other_cnn_planes(t)
         return get(cal["terms3x3"])
 
     def compute_dtype(self, mode):
@@ -469,7 +493,9 @@ class Renderer:
         if t3 is None:
             t3 = (f"{cal['terms3x3']}-term (auto: 1-term vs 3-term image differed by {cal['max_abs_diff_1term_vs_3term']:.1e} <= "
                   f"{cal['bound']:.0e} on the style's first frame)" if cal and cal["terms3x3"] == 1 else
-                  f"3-term (auto: the 1-term form differed by {cal['max_abs_diff_1term_vs_3term']:.1e} > {cal['bound']:.0e})" if cal
+                  f"3-term (auto: the 1-term form differed by {cal['max_abs_diff_1term_vs_3term']:.1e} > {cal['bound']:.0e})" if cal and cal["terms3x3"] == 3
+                  else f"per layer (conv2a, conv2b, conv3a, conv3b) = {cal['terms3x3']} terms (auto: the cheapest rung inside the gate; "
+                       f"all-1-term differed by {cal['max_abs_diff_1term_vs_3term']:.1e} > {cal['bound']:.0e})" if cal
                   else "auto (1-term if within 5e-4 of the 3-term image, not yet calibrated)")
         else:
             t3 = f"{t3}-term (set explicitly)"
@@ -635,9 +661,16 @@ class Renderer:
         """Relative cost of every OUTPUT row of the frame, for cutting it into bands of equal work (dist.balanced_row_bands):
         the field kernel visits only rays that hit something (sky rows cost almost nothing there), every ray costs ray casting,
         sky MLP and CNN.  Estimated from a 1/scale-resolution ray cast of the padded frame (1/16 of the rays; deterministic and
-        bit-identical on every rank, so all ranks cut the same bands without talking): cost(row) = hits(row) + MISS_COST * width."""
+        bit-identical on every rank, so all ranks cut the same bands without talking): cost(row) = hits(row) + MISS_COST * width.
+        The result is kept per (pose, resolution): a trajectory that is rendered again -- or the stats frame of bench.py -- pays
+        the low-resolution ray cast and its device -> host read once."""
         cam_ori, cam_dir, cam_up, cam_f = pose
         H, W = resolution_hw
+        key = (tuple(np.asarray(cam_ori, np.float64).reshape(-1).tolist()), tuple(np.asarray(cam_dir, np.float64).reshape(-1).tolist()),
+               tuple(np.asarray(cam_up, np.float64).reshape(-1).tolist()), float(cam_f), int(H), int(W), int(scale), id(self.volume))
+        cache = self.__dict__.setdefault("_row_cost_cache", {})
+        if key in cache:
+            return cache[key]
         f, c, cam_res = frame_intrinsics(cam_f, resolution_hw, self.pad)
         Hq, Wq = -(-cam_res[0] // scale), -(-cam_res[1] // scale)
         off = (scale - 1) / 2.0
@@ -646,7 +679,10 @@ class Renderer:
                                                                [(c[0] - off) / scale, (c[1] - off) / scale], [Hq, Wq], 1, palette=self.palette)
             hits_q = (vid.view(Hq, Wq) != 0).sum(dim=1).cpu().numpy().astype(np.float64) * scale      # hits per padded row, estimated
         pad_rows = np.minimum(np.arange(H) + self.pad // 2, cam_res[0] - 1)       # the padded row at the centre of output row r's apron
-        return hits_q[pad_rows // scale] + MISS_COST * cam_res[1]
+        while len(cache) >= 512:
+            cache.pop(next(iter(cache)))
+        cache[key] = hits_q[pad_rows // scale] + MISS_COST * cam_res[1]
+        return cache[key]
 
     def band_prepare(self, pose, resolution_hw, row0, row1, mode="fused", apron="minimal"):
         """Cast the rays needed for output rows [row0,row1) and evaluate the sky MLP on them.  Returns a handle with the band's

@@ -5,7 +5,7 @@ Python layers pinned by the goldens) and compared with the same pixels of the fu
 the image (north star).  Config 2 is checked on ONE WHOLE FRAME (all 40 tiles, ~1-2 min of CPU) plus sampled tiles of
 other poses, on the very path bench.py times (compact uint8 volume + pipelined render_frames + minimal apron); configs
 3 and 5 on sampled tiles (of 135 / 510), always including a frame corner, and for config 5 two tiles on every row-band seam
-of the tile-parallel renderer (32 tiles)."""
+of the tile-parallel renderer as it cuts the bands in production (work-balanced; 32 tiles)."""
 import numpy as np
 import pytest
 import torch
@@ -111,19 +111,22 @@ def test_config2_bench_path_other_pose_tiles_against_oracle(big, bench_path, lut
 
 
 def test_config5_every_band_seam_against_oracle(big, lut):
-    """BASELINE config 5 (3840x2160, 40 samples/ray): the frame rendered as 8 row bands exactly as
-    dist.render_frame_tile_parallel does on 8 ranks (band_prepare on every band -- minimal apron --, the frame-wide sky mean
-    stitched from the bands' sums, band_finish), against 32 of the 510 oracle tiles: two tiles on EVERY one of the 7 band seams
-    (rows 270, 540, ... 1890), the four frame corners (with the ragged last row / column of the reference's 17 x 30 tile grid),
-    and 14 more spread over the frame (seeded) -- max abs error recorded for profiles/."""
+    """BASELINE config 5 (3840x2160, 40 samples/ray): the frame rendered as 8 row bands CUT WHERE PRODUCTION CUTS THEM
+    (dist.render_frame_tile_parallel on 8 ranks: balanced_row_bands on Renderer.row_costs -- bands of equal estimated work, not of
+    equal height), band_prepare on every band -- minimal apron --, the frame-wide sky mean stitched from the bands' sums,
+    band_finish; against 32 of the 510 oracle tiles: two tiles on EVERY one of the 7 actual band seams (the reference tile row that
+    holds the seam's output row), the four frame corners (with the ragged last row / column of the reference's 17 x 30 tile grid),
+    and more spread over the frame (seeded) -- max abs error recorded for profiles/."""
     import json
     import os
+    from scenedreamer_amd.dist import balanced_row_bands, row_bands
     R, scene, poses, w, vox_np = big
     hw, ns, world = (2160, 3840), 40, 8
+    bands = balanced_row_bands(R.row_costs(poses[17], hw), world)
+    assert bands[0][0] == 0 and bands[-1][1] == hw[0] and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+    assert bands != row_bands(hw[0], world)                                    # the work-balanced cut is a different one
 
     def render(_R, pose):
-        from scenedreamer_amd.dist import row_bands
-        bands = row_bands(hw[0], world)
         hds = [R.band_prepare(pose, hw, r0, r1, mode="fused") for r0, r1 in bands]
         tot, cnt = sum(h["sky_sum"] for h in hds), sum(h["sky_cnt"] for h in hds)
         sky_avg = (tot / cnt).to(torch.float32)
@@ -131,11 +134,14 @@ def test_config5_every_band_seam_against_oracle(big, lut):
 
     def tiles(nh, nw):
         assert (nh, nw) == (17, 30)
-        seams = [(270 * k) // 128 for k in range(1, world)]                 # the tile row that holds output row 270 k
-        assert seams == [2, 4, 6, 8, 10, 12, 14]
+        seams = [b[0] // 128 for b in bands[1:]]                               # the tile row that holds the first row of band k
         rng = np.random.default_rng(5)
-        t = [(ih, int(c)) for ih in seams for c in rng.choice(nw, 2, replace=False)]
-        t += [(0, 0), (0, nw - 1), (nh - 1, 0), (nh - 1, nw - 1)]
+        t = []
+        for ih in seams:
+            for c in rng.choice(nw, 2, replace=False):
+                if (ih, int(c)) not in t:
+                    t.append((ih, int(c)))
+        t += [c for c in ((0, 0), (0, nw - 1), (nh - 1, 0), (nh - 1, nw - 1)) if c not in t]
         while len(t) < 32:
             cand = (int(rng.integers(nh)), int(rng.integers(nw)))
             if cand not in t:
@@ -145,7 +151,8 @@ def test_config5_every_band_seam_against_oracle(big, lut):
     worst = _check_tiles(big, lut, hw, ns, 17, tiles, 510, render=render, allow_flat=True)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/config5_tiles_error.json", "w") as f:
-        json.dump({"config": "3840x2160x40, scene 2048, pose 17 of 40, 8 row bands; 32 (+ the sky-most) of 510 tiles incl. two on every band seam",
+        json.dump({"config": "3840x2160x40, scene 2048, pose 17 of 40, 8 work-balanced row bands (dist.balanced_row_bands, as render_frame_tile_parallel "
+                             "cuts them); 32 (+ the sky-most) of 510 tiles incl. two on every band seam", "bands": [list(b) for b in bands],
                    "max_abs_err": worst}, f)
 
 
@@ -188,3 +195,29 @@ def test_row_bands_equal_full_frame(big, terms3x3, bound):
     d = float((img - full).abs().max())
     print(f"row bands vs full frame, terms3x3={terms3x3}: max abs diff {d:.2e}")
     assert d < bound
+
+
+@pytest.mark.parametrize("bias", [200.0, 4000.0])
+def test_config2_surface_like_weights_against_oracle(big, lut, bias):
+    """Every precision gate and the early-termination default were tuned on random-init density (about half the samples have
+    sigma <= 0, 1 % of the passes terminate).  A trained field has surfaces: here the density head is biased so that the rays
+    saturate inside the first voxels they hit and most passes of a 32-ray group are dropped by the wavefront-ballot termination
+    (default term_eps) -- the regime a released checkpoint would run in.  Four config-2 tiles against the CPU oracle (which
+    evaluates every sample), same 1e-3 bound; the fraction of dropped passes is asserted, so the test cannot pass by not
+    terminating."""
+    from scenedreamer_amd import synth
+    from scenedreamer_amd.renderer import Renderer
+    R, scene, poses, w, vox_np = big
+    w2 = dict(w)
+    w2["render_net.fc_sigma.bias"] = np.asarray(w["render_net.fc_sigma.bias"]) + np.float32(bias)
+    R2 = Renderer(w2, scene, "cuda")
+    R2.set_style(synth.make_style(8888))
+    hw, ns, pi = (540, 960), 24, 26
+    worst = _check_tiles((R2, scene, poses, w2, vox_np), lut, hw, ns, pi, lambda nh, nw: [(0, 0), (nh - 1, nw - 1), (nh // 2, nw // 2), (1, 2)], 40)
+    B, hit, ev = R2.field_work([poses[pi]], hw, ns, "minimal")
+    dropped = ev["passes_skipped_by_termination"] / max(ev["passes_of_visited_groups"], 1.0)
+    gate = {k: v for k, v in (R2.field_gate or {}).items() if k != "measurements"}
+    print(f"surface-like weights (fc_sigma.bias + {bias:g}): {100 * dropped:.1f} % of the visited groups' passes dropped by early termination, "
+          f"colour branch skipped in {100 * ev.get('colour_samples', 0) / max(ev['evaluated_samples'], 1):.1f} % -> ran; max abs err vs oracle {worst:.3e}; gate {gate}")
+    assert R2.field_gate is not None and R2.field_gate.get("path", "fused") == "fused", R2.field_gate
+    assert dropped > 0.5

@@ -92,7 +92,7 @@ def test_two_ranks_on_one_gpu_equal_single_process():
     # that can flip an f16 rounding in the CNN, so the bound is the CNN's own error level (test_row_bands_equal_full_frame)
     d = float(np.abs(res[0][2] - tp_single).max())
     print(f"tile-parallel over 2 ranks vs single process: max abs diff {d:.2e} (CNN 3x3 terms {cal['terms3x3']})")
-    assert d < (5e-4 if cal["terms3x3"] == 1 else 1e-6)
+    assert d < (5e-4 if cal["terms3x3"] != 3 else 1e-6)
 
 
 def _worker8(rank, world, port, q):

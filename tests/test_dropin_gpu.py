@@ -374,3 +374,56 @@ def test_unmodified_inference_loop_on_the_fused_kernels(scene256, weights_full, 
           f"{100 * off:.2f} % of the values differ; stats {b.stats}")
     assert worst <= 1 and off < 0.2
     assert os.path.exists(os.path.join(str(tmp_path / "ref"), "rgb_render", "00002.png"))
+
+
+@pytest.mark.needs_reference
+def test_unmodified_loop_at_the_headline_config_against_oracle_tiles(weights_full, lut, tmp_path):
+    """BASELINE config 2 (960x540, 24 samples/ray, scene 2048) through the reference's OWN loop, default tile_size 128: the binding
+    evaluates the padded frame once when the first of its 40 tiles arrives and serves the tiles as views (dropin.frame_field /
+    frame_image_tile).  The loop's float pixels (the frame the views are cut from, before the loop's uint8 conversion) against the
+    CPU oracle on 5 tiles of the reference's tile grid -- two frame corners incl. the ragged edge tile, the centre, two more."""
+    from loop_helpers import run_reference_loop
+    from oracle import field_ref as FR
+    from scenedreamer_amd import camera, dropin, synth
+    scene = synth.make_scene(2048, 3407)
+    G, _ = _generator(weights_full, scene, fast=True)
+    hw, ns, steps = [540, 960], 24, 3
+    b = dropin.binding(G)
+    got = []
+    b.on_frame = lambda fr: got.append((fr["img"].clone(), fr["net_out"].shape))
+    try:
+        frames = run_reference_loop(G, str(tmp_path / "ref"), hw, ns, steps, tile_size=128)
+    finally:
+        b.on_frame = None
+    assert len(got) == steps and b.stats["frames_coalesced"] == steps and b.stats["tiles_from_frame"] == 40 * steps, b.stats
+    assert b.stats["perpix_reference"] == 0 and b.stats["global_reference"] == 0, b.stats
+    img, no_shape = got[-1]
+    assert tuple(no_shape) == (1, 570, 990, 64) and tuple(img.shape) == (1, 3, 570, 990)
+    img = img[:, :, 15:-15, 15:-15].cpu().numpy()
+    # the uint8 frame the loop handed to its writer is this float image
+    u8 = np.clip(np.floor((np.transpose(img[0], (1, 2, 0)) * 0.5 + 0.5) * 255), 0, 255).astype(np.int32)    # write_img truncates (scenedreamer.py:513)
+    assert np.abs(u8 - frames[-1].astype(np.int32)).max() <= 1
+    pose = camera.eval_camera_poses(scene, maxstep=steps, pattern=0, cam_ang=72)[steps - 1]
+    R_z = G.style_net(torch.from_numpy(np.asarray(synth.make_style(8888))).cuda())
+    from scenedreamer_amd.renderer import Renderer
+    R = Renderer(weights_full, scene, "cuda")
+    R.set_style(synth.make_style(8888))
+    assert float((R.z - R_z).abs().max()) < 1e-5
+    tiles = [(0, 0), (4, 7), (2, 3), (1, 6), (3, 1)]
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    ref = FR.render_frame_tiled(weights_full, lut, scene.voxel_t.numpy(), (pose[0].numpy(), pose[1].numpy(), pose[2].numpy(), pose[3]),
+                                tuple(hw), ns, R.z.cpu().numpy(), R.global_enc.cpu().numpy(), tiles=tiles)
+    worst = 0.0
+    for t in tiles:
+        r0, c0, tile = ref[t]
+        tile = tile.numpy()
+        e = float(np.abs(img[:, :, r0:r0 + tile.shape[2], c0:c0 + tile.shape[3]] - tile).max())
+        worst = max(worst, e)
+        assert np.isfinite(tile).all(), t
+    print(f"unmodified inference_givenstyle, 960x540x24, scene 2048, tile_size 128 (frame evaluated once): max abs err vs oracle on {len(tiles)} tiles {worst:.3e}")
+    import json
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/dropin_loop_error.json", "w") as f:
+        json.dump({"config": "960x540x24, scene 2048, unmodified inference_givenstyle on install_shims(fast=True), tile_size 128, frame evaluated once "
+                             "for its 40 tiles; last of 3 frames", "tiles": [list(t) for t in tiles], "max_abs_err": worst}, f)
+    assert worst < TOL

@@ -394,9 +394,26 @@ def test_precision_decisions_follow_the_measurements():
     g = R.adopt_precision(meas(explicit_colour=3, explicit_cnn=1, explicit_sky=3, field_err={3: 5e-4}, image_err={1: 4e-4}))
     assert g["colour"] == {"terms": 3, "set_explicitly": True} and R.colour_terms_auto is None and R.cnn_calibration is None
     assert g["sky"]["set_explicitly"] and R.sky_terms_auto is None
+    # the ladder between "all one product" and "all 3-term" (cnn.CNN_LADDER): the cheapest rung inside both bounds is taken
+    ladder = dict(cnn_diff=6e-4, cnn_diffs={1: 6e-4, "1113": 4.5e-4, "1133": 3e-4}, image_err={1: 7e-4, "1113": 5e-4, "1133": 4e-4, 3: 2e-4})
+    g = R.adopt_precision(meas(**ladder))
+    assert R.cnn_calibration["terms3x3"] == "1113" and g["path"] == "fused" and g["image_err_vs_fp32"] == 5e-4
+    g = R.adopt_precision(meas(**dict(ladder, cnn_diffs={1: 6e-4, "1113": 5.5e-4, "1133": 3e-4})))
+    assert R.cnn_calibration["terms3x3"] == "1133" and g["image_err_vs_fp32"] == 4e-4
+    g = R.adopt_precision(meas(**dict(ladder, image_err={1: 9e-4, "1113": 8.5e-4, "1133": 8.1e-4, 3: 2e-4})))
+    assert R.cnn_calibration["terms3x3"] == 3 and g["path"] == "fused"
     R.cnn_auto_bound = 1e-7
     R.adopt_precision(meas())
     assert R.cnn_calibration["terms3x3"] == 3 and R.cnn_calibration["bound"] == 1e-7
+
+
+def test_cnn_forms():
+    from scenedreamer_amd.cnn import CNN_LADDER, form_cost, form_key, form_terms
+    assert form_key(1) == 1 and form_key("1111") == 1 and form_key((3, 3, 3, 3)) == 3 and form_key([1, 1, 1, 3]) == "1113"
+    assert form_terms("1133") == (1, 1, 3, 3) and form_terms(3) == (3, 3, 3, 3)
+    assert [form_cost(f) for f in CNN_LADDER] == sorted(form_cost(f) for f in CNN_LADDER) and CNN_LADDER[0] == 1 and CNN_LADDER[-1] == 3
+    with pytest.raises(AssertionError):
+        form_key("113")
 
 
 def test_trunk_weight_range_is_checked_before_packing():

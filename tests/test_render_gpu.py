@@ -127,11 +127,12 @@ def test_ray_chunking_is_bit_identical(renderer, scene256, monkeypatch):
     assert torch.equal(a, b)        # and both equal the single-kernel field (the default) that rendered `a`
 
 
-@pytest.mark.parametrize("terms3x3,bound", [(3, 2e-4), (1, 8e-4)])
+@pytest.mark.parametrize("terms3x3,bound", [(3, 2e-4), (1, 8e-4), ("1113", 8e-4), ("1133", 8e-4)])
 def test_mfma_cnn_matches_torch_cnn(renderer, terms3x3, bound):
     """RenderCNN on the MFMA kernels vs the same network through PyTorch/MIOpen fp32, frames with ragged edges.
     terms3x3 = 3: every product as the 3-term f16 split; terms3x3 = 1 (the default profile): the four 3x3 layers as a
-    single round-to-nearest f16 product (tools/precision_study.py predicts ~7e-5 rms, < 5e-4 max)."""
+    single round-to-nearest f16 product (tools/precision_study.py predicts ~7e-5 rms, < 5e-4 max); "1113" / "1133": the rungs in
+    between (cnn.CNN_LADDER: conv3b, or conv3a + conv3b, 3-term -- a 1-term conv3a then hands conv3b a hi plane only)."""
     from scenedreamer_amd.cnn import MfmaCNN
     torch.manual_seed(0)
     for hw in ((37, 53), (64, 96), (128, 200), (300, 520)):   # the last: 627 patches on 256 workgroups (patch transitions)
@@ -141,6 +142,25 @@ def test_mfma_cnn_matches_torch_cnn(renderer, terms3x3, bound):
         err = (got - ref).abs()
         print(f"MFMA CNN terms3x3={terms3x3} {hw}: max abs err {err.max().item():.2e}, rms {err.pow(2).mean().sqrt().item():.2e}")
         assert got.shape == ref.shape and err.max().item() < bound, f"max abs err {err.max().item():.3e}"
+
+
+def test_cnn_ladder_trades_time_for_error(renderer):
+    """cnn.CNN_LADDER on one 960x540-sized input: the error against the 3-term image shrinks and the time grows rung by rung
+    (what Renderer.calibrate_style picks from: the cheapest rung inside its bounds)."""
+    from scenedreamer_amd.cnn import CNN_LADDER, MfmaCNN
+    from scenedreamer_amd.renderer import _time_ms
+    torch.manual_seed(1)
+    x = torch.rand(1, 548, 968, 64, device="cuda") * 2 - 1
+    forms = {f: MfmaCNN(renderer, f) for f in CNN_LADDER}
+    ref = forms[3](x).clone()
+    rows = []
+    for f in CNN_LADDER:
+        img = forms[f](x).clone()
+        rows.append((f, float((img - ref).abs().max()), _time_ms(lambda: forms[f](x), 5)))
+    print("CNN ladder at 968x548: " + "; ".join(f"{f}: vs 3-term {e:.2e}, {ms:.2f} ms" for f, e, ms in rows))
+    errs, times = [r[1] for r in rows], [r[2] for r in rows]
+    assert errs[-1] == 0.0 and errs[0] > errs[2] > 0 and errs[0] >= errs[1] * 0.95
+    assert times[0] < times[1] < times[2] < times[3]
 
 
 def test_cnn_tail_as_one_chain_equals_the_three_launches(renderer):
