@@ -41,6 +41,7 @@ class Backend:
     and addresses, so packed weights are rebuilt exactly when they are stale."""
     mfma_cnn = Renderer.mfma_cnn
     _cnn_form = Renderer._cnn_form
+    _drop_other_cnn_planes = Renderer._drop_other_cnn_planes
     set_precision = Renderer.set_precision
 
     def __init__(self):

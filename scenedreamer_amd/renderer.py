@@ -1016,7 +1016,7 @@ CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (con
 
 
 L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md: 4 MiB per XCD, ~34.5 TB/s aggregate
-PMC_PROFILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
+PMC_PROFILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
 
 
 def _profiled_traffic():

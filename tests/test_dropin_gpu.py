@@ -389,12 +389,26 @@ def test_unmodified_loop_at_the_headline_config_against_oracle_tiles(weights_ful
     G, _ = _generator(weights_full, scene, fast=True)
     hw, ns, steps = [540, 960], 24, 3
     b = dropin.binding(G)
-    got = []
+    got, cams = [], []
     b.on_frame = lambda fr: got.append((fr["img"].clone(), fr["net_out"].shape))
+    # the camera the LOOP uses: EvalCameraController runs on the generator's own voxel handle, whose trans_mat is a registered buffer
+    # and moved to the GPU with the generator (camctl.py:9-60) -- its matrix products there round differently from the host's
+    # (cam_ori 32.999996 instead of 33.0 on this scene), and the field is chaotic in such an ulp at a few dozen rays per frame
+    # (tools/dbg_dropin_err.py: 22 rays > 1e-3 on net_out).  The oracle is given the very poses the loop's ray caster received.
+    import sys
+    voxlib = sys.modules["imaginaire.generators.scenedreamer"].voxlib      # (the package object the loop's module bound at import)
+    rvip = voxlib.ray_voxel_intersection_perspective
+
+    def recording_rvip(voxel_t, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples):
+        cams.append((torch.as_tensor(cam_ori).detach().cpu().numpy().astype(np.float32), torch.as_tensor(cam_dir).detach().cpu().numpy().astype(np.float32),
+                     torch.as_tensor(cam_up).detach().cpu().numpy().astype(np.float32), float(cam_f)))
+        return rvip(voxel_t, cam_ori, cam_dir, cam_up, cam_f, cam_c, img_dims, max_samples)
+    voxlib.ray_voxel_intersection_perspective = recording_rvip
     try:
         frames = run_reference_loop(G, str(tmp_path / "ref"), hw, ns, steps, tile_size=128)
     finally:
         b.on_frame = None
+        voxlib.ray_voxel_intersection_perspective = rvip
     assert len(got) == steps and b.stats["frames_coalesced"] == steps and b.stats["tiles_from_frame"] == 40 * steps, b.stats
     assert b.stats["perpix_reference"] == 0 and b.stats["global_reference"] == 0, b.stats
     img, no_shape = got[-1]
@@ -404,6 +418,9 @@ def test_unmodified_loop_at_the_headline_config_against_oracle_tiles(weights_ful
     u8 = np.clip(np.floor((np.transpose(img[0], (1, 2, 0)) * 0.5 + 0.5) * 255), 0, 255).astype(np.int32)    # write_img truncates (scenedreamer.py:513)
     assert np.abs(u8 - frames[-1].astype(np.int32)).max() <= 1
     pose = camera.eval_camera_poses(scene, maxstep=steps, pattern=0, cam_ang=72)[steps - 1]
+    assert len(cams) == steps and cams[-1][3] == pose[3] * (hw[1] - 1)                      # the intrinsics are host arithmetic: equal
+    assert max(float(np.abs(cams[-1][k] - pose[k].numpy()).max()) for k in range(3)) < 1e-5   # the extrinsics: equal to an ulp or so
+    pose = (torch.from_numpy(cams[-1][0]), torch.from_numpy(cams[-1][1]), torch.from_numpy(cams[-1][2]), pose[3])
     R_z = G.style_net(torch.from_numpy(np.asarray(synth.make_style(8888))).cuda())
     from scenedreamer_amd.renderer import Renderer
     R = Renderer(weights_full, scene, "cuda")

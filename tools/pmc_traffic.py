@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Per-launch HBM traffic / MFMA busy of the hot kernels from the rocprofv3 PMC passes of tools/prof_round.sh.
 
-    python tools/pmc_traffic.py <fetch.db> <write.db> <mfma.db> <commit> > profiles/rNN_pmc_traffic.json
+    python tools/pmc_traffic.py <fetch.db> <write.db> <mfma.db> <commit> [<fetch2.db> <write2.db>] > profiles/rNN_pmc_traffic.json
+
+(fetch2 / write2: the same two passes on the TWO-KERNEL form of the field, SDN_FIELD_SINGLE_KERNEL=0 -- the only launches of
+encode_kernel, the stand-alone grid sampler, and of mlp_kernel<.., 0>.)
 
 Corrections as MI355X_MICROARCH.md (HBM section) prescribes: FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 reports half the bytes of wide (16 B/lane) coalesced streaming reads -> doubled for the kernels whose reads are such
@@ -44,9 +47,12 @@ def pick(rows, key, counter):
     return None, 0
 
 
-def main(fetch_db, write_db, mfma_db, commit):
+def main(fetch_db, write_db, mfma_db, commit, fetch2_db=None, write2_db=None):
     f_rows, _ = counters(fetch_db)
     w_rows, _ = counters(write_db)
+    if fetch2_db and write2_db:     # kernels that only the two-kernel form launches: appended, so the one-kernel passes win on a tie
+        f_rows = list(f_rows) + list(counters(fetch2_db)[0])
+        w_rows = list(w_rows) + list(counters(write2_db)[0])
     m_rows, m_dur = counters(mfma_db)
     from scenedreamer_amd import build
     out = {"commit": commit,
@@ -81,4 +87,4 @@ def main(fetch_db, write_db, mfma_db, commit):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:7])

@@ -16,7 +16,10 @@ timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $P/w -o w -- python $R/
 python $R/tools/rocpd_stats.py $P/w/w_results.db 8 _kernel > $R/gpurun_out/${T}_pmc_write.md
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_WAIT_ANY GRBM_GUI_ACTIVE -d $P/m -o m -- python $R/tools/frame_once.py fused 3 >> $R/gpurun_out/prof.log 2>&1
 python $R/tools/rocpd_stats.py $P/m/m_results.db 8 _kernel > $R/gpurun_out/${T}_pmc_mfma.md
-python $R/tools/pmc_traffic.py $P/f/f_results.db $P/w/w_results.db $P/m/m_results.db "$1" > $R/gpurun_out/${T}_pmc_traffic.json
+# the stand-alone grid sampler (encode_kernel) only exists in the two-kernel form of the field: two more passes for its DRAM bytes
+SDN_FIELD_SINGLE_KERNEL=0 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $P/f2 -o f2 -- python $R/tools/frame_once.py fused 3 >> $R/gpurun_out/prof.log 2>&1
+SDN_FIELD_SINGLE_KERNEL=0 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $P/w2 -o w2 -- python $R/tools/frame_once.py fused 3 >> $R/gpurun_out/prof.log 2>&1
+python $R/tools/pmc_traffic.py $P/f/f_results.db $P/w/w_results.db $P/m/m_results.db "$1" $P/f2/f2_results.db $P/w2/w2_results.db > $R/gpurun_out/${T}_pmc_traffic.json
 cd $R
 cp gpurun_out/${T}_pmc_traffic.json profiles/${T}_pmc_traffic.json
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_final.json 2> gpurun_out/bench_final.err; echo bench rc=$?
