@@ -197,11 +197,17 @@ int sdn_field_pack_weights_mx(const float *w1, const float *const *wh5_host, con
  * tensor / Python scalar) is evaluated: 0 = multiplication by the float32 reciprocal, what PyTorch does on a CUDA tensor
  * (the reference's GPU path); 1 = IEEE division, what PyTorch does on a CPU tensor (the goldens recorded from the
  * reference's CPU run).  They differ by at most 1 ulp, and only when nsamples is not a power of two.
- * window_host: NULL (the n_rays rays are rays 0..n_rays-1 of voxel_id / depth2 / raydirs), or host int32[5]
- *   {n_src, pitch, first, cols, ray0}: the arrays hold n_src rays (the whole padded frame the ray marcher wrote, as the
- *   reference's per-frame voxlib call does, scenedreamer.py:576-590) and local ray r is ray w = ray0 + r of a window of
+ * window_host: NULL (the n_rays rays are rays 0..n_rays-1 of voxel_id / depth2 / raydirs), or host int32[6]
+ *   {n_src, pitch, first, cols, ray0, blocked}: the arrays hold n_src rays (the whole padded frame the ray marcher wrote, as
+ *   the reference's per-frame voxlib call does, scenedreamer.py:576-590) and local ray r is ray w = ray0 + r of a window of
  *   `cols` columns whose ray (y, x) is source ray first + y * pitch + x (cols = 0: source ray = ray0 + r).  Outputs
- *   (feat, dist, label, rayflag) and u_dev are indexed by the LOCAL ray. */
+ *   (feat, dist, label, rayflag) are indexed by the LOCAL ray.
+ *   blocked != 0 (needs ray0 = 0, cols = 8k, n_rays = cols x 4m: the launch is the whole window): the launch's ray ORDER is 8 x 4
+ *   pixel blocks instead of row-major -- the 32 rays a workgroup takes through a pass together are neighbours in both directions,
+ *   so a group's all-or-nothing savings (colour-branch skipping, early termination) apply more often; per-ray results are the
+ *   same bits, the per-ray outputs and inputs that are not read through the window (net_out, the sdn_field_aux arrays, u_dev) stay
+ *   in the window's row-major order; `passes` / `colour_passes` then count per block.  sdn_field_encode and sdn_field_mlp of one
+ *   frame must be given the same value. */
 int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,

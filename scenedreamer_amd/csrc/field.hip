@@ -102,13 +102,34 @@ constexpr int C_TOTAL = C_SKY_AVG + OUTC;
 // evaluated on the 4-px apron the image can depend on, a band of rows, or a chunk of either): local ray r is ray
 // w = ray0 + r of a window of `cols` columns whose ray (y, x) is source ray first + y * pitch + x.  No window: cols = 0,
 // source ray = ray0 + r.  Reading through the window replaces four strided-slice copies per frame on the host side.
+//
+// Ray ORDER of a launch (tiled_bx > 0): launch-local ray r is not pixel r of the window in row-major order but pixel
+//   (4 * (b / tiled_bx) + (r & 31) / 8,  8 * (b % tiled_bx) + (r & 7)),  b = r / 32:
+// the 32 rays a workgroup takes through a pass together (4 waves x 8 rays) are an 8 x 4 pixel BLOCK instead of 32 consecutive
+// pixels of a row.  What a group can leave out -- the colour branch of a pass whose samples all have weight zero, the passes
+// behind its last ray's saturation -- it leaves out when ALL its rays agree, and rays that are neighbours in both directions
+// agree more often: measured on the benchmark frames 36 -> 40 %, 34 -> 40 %, 23 -> 32 % of the passes without colour branch
+// (tools/dbg_sigma_stats.py).  A wave still reads 8 consecutive rays of a row (the same coalescing), rays are independent
+// (net_out is the same bits per ray, only its per-group statistics move), the per-ray OUTPUTS stay in the window's row-major
+// order (out_row).  The host sets it when the launch covers a whole window of 8k columns x 4m rows.
 struct RayWindow {
     int32_t n_src;             // rays in the source arrays (stride of depth2's two planes)
     int32_t pitch, first, cols, ray0;
-    __device__ __forceinline__ int src(int r) const {
+    int32_t tiled_bx;          // 0: row-major ray order; else 8 x 4 pixel blocks, this many per block row (= cols / 8)
+    // window-local pixel index (row-major) of launch-local ray r
+    __device__ __forceinline__ int pix(int r) const {
         const int w = ray0 + r;
-        return cols > 0 ? first + (w / cols) * pitch + (w % cols) : w;
+        if (tiled_bx == 0) return w;
+        const int b = w >> 5, by = b / tiled_bx, bxi = b - by * tiled_bx;
+        return (4 * by + ((w & 31) >> 3)) * cols + 8 * bxi + (w & 7);
     }
+    __device__ __forceinline__ int src(int r) const {
+        const int q = pix(r);
+        return cols > 0 ? first + (q / cols) * pitch + (q % cols) : q;
+    }
+    // row of launch-local ray r in the launch's per-ray outputs / inputs that are NOT read through the window (net_out, the
+    // per-sample outputs, the stratified randoms u): r itself, or -- tiled, where ray0 == 0 -- the pixel's row-major index
+    __device__ __forceinline__ int out_row(int r) const { return tiled_bx == 0 ? r : pix(r); }
 };
 
 
@@ -523,7 +544,7 @@ struct EncSample {
 __device__ __forceinline__ EncSample enc_place(const EncParams &p, const RayBoxes &rb, const float (&d)[3], int rl, int sidx, bool ray_ok) {
     EncSample e;
     e.valid = ray_ok && sidx < p.ns;
-    const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)rl * (p.ns + 1) : nullptr, p.ieee_div ? -(p.ns + 1) : p.ns + 1,
+    const Placed pl = place_sample(rb, p.M, p.lin, p.u ? p.u + (size_t)p.win.out_row(rl) * (p.ns + 1) : nullptr, p.ieee_div ? -(p.ns + 1) : p.ns + 1,
                                    e.valid ? sidx : 0, p.sample_depth);
     const float wx = mul_add_exact(d[0], pl.depth, p.ori[0]);  // scenedreamer.py:354
     const float wy = mul_add_exact(d[1], pl.depth, p.ori[1]);
@@ -2030,7 +2051,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             if constexpr (AUX) {   // the per-sample return values of Generator._forward_perpix
                 const int sidx = ch * SAMP_PER_STEP + q;
                 if (ray_ok && sidx < p.ns) {
-                    const size_t smp = (size_t)ray * p.ns + sidx;
+                    const size_t smp = (size_t)p.win.out_row(ray) * p.ns + sidx;
                     if (h == 0) {
                         if (p.w_out) p.w_out[smp] = (flag & 1) ? 0.f : wgt;
                         if (p.depth_out) p.depth_out[smp] = smp_depth;
@@ -2123,13 +2144,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                     const float rgb_sky = fminf(fmaxf(sky, -1.f), 1.f) + 1.f;
                     o[e] = (sky_only ? 0.f : outq[ib][e]) + sky_w * rgb_sky - 1.f;       // :410-413
                     if constexpr (AUX) {
-                        if (p.skyb_out) p.skyb_out[(size_t)ray * OUTC + f0 + e] = sky;
+                        if (p.skyb_out) p.skyb_out[(size_t)p.win.out_row(ray) * OUTC + f0 + e] = sky;
                     }
                 }
                 if constexpr (AUX) {
-                    if (p.nosky_out && ib == 0 && q == 0 && h == 0) p.nosky_out[ray] = nosky ? 1 : 0;
+                    if (p.nosky_out && ib == 0 && q == 0 && h == 0) p.nosky_out[p.win.out_row(ray)] = nosky ? 1 : 0;
                 }
-                *reinterpret_cast<float4 *>(p.net_out + (size_t)ray * OUTC + f0) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4 *>(p.net_out + (size_t)p.win.out_row(ray) * OUTC + f0) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
         }   // !RAW
@@ -2945,6 +2966,7 @@ size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples) {
 
 // window_host: NULL, or {n_src, pitch, first, cols, ray0} (see RayWindow)
 static int set_window(RayWindow &w, const int32_t *window_host, int32_t n_rays, const char *who) {
+    w.tiled_bx = 0;
     if (window_host == nullptr) {
         w.n_src = n_rays; w.pitch = 0; w.first = 0; w.cols = 0; w.ray0 = 0;
         return 0;
@@ -2952,6 +2974,11 @@ static int set_window(RayWindow &w, const int32_t *window_host, int32_t n_rays, 
     w.n_src = window_host[0]; w.pitch = window_host[1]; w.first = window_host[2]; w.cols = window_host[3]; w.ray0 = window_host[4];
     if (w.n_src <= 0 || w.cols < 0 || w.ray0 < 0 || w.first < 0 || w.pitch < 0)
         return sdn::fail(SDN_ERR_INVALID, "%s: bad ray window", who);
+    if (window_host[5]) {   // 8 x 4 pixel blocks: the launch is the whole window, whole blocks only
+        if (!(w.cols > 0 && w.cols % 8 == 0 && w.ray0 == 0 && n_rays % w.cols == 0 && (n_rays / w.cols) % 4 == 0))
+            return sdn::fail(SDN_ERR_INVALID, "%s: the blocked ray order needs a whole window of 8k columns x 4m rows (ray0 = 0)", who);
+        w.tiled_bx = w.cols / 8;
+    }
     const long last = (long)w.ray0 + n_rays - 1;
     const long src_last = w.cols > 0 ? (long)w.first + (last / w.cols) * w.pitch + (w.cols - 1) : last;
     if (src_last >= w.n_src) return sdn::fail(SDN_ERR_INVALID, "%s: ray window reaches outside the %d source rays", who, w.n_src);
@@ -3155,7 +3182,7 @@ int sdn_render_mlp(const float *x, const uint8_t *label, const void *packed, con
     p.R = (int32_t)n_rows; p.ns = 32; p.nch = 8;
     p.n_tiles = (int32_t)((n_rows + 255) / 256);
     p.term_depth = 0.f; p.passes = nullptr;
-    p.win.n_src = p.R; p.win.pitch = 0; p.win.first = 0; p.win.cols = 0; p.win.ray0 = 0;
+    p.win.n_src = p.R; p.win.pitch = 0; p.win.first = 0; p.win.cols = 0; p.win.ray0 = 0; p.win.tiled_bx = 0;
     p.sky_avg = nullptr; p.ticket = ticket;
     p.cam_ori_dev = nullptr; p.w_out = nullptr; p.depth_out = nullptr; p.sigma_out = sigma;
     p.sig_out = nullptr; p.col_out = nullptr; p.skyb_out = nullptr; p.nosky_out = nullptr;

@@ -11,7 +11,7 @@ from . import capi
 
 _f2 = ctypes.c_float * 2
 _f3 = ctypes.c_float * 3
-_i5 = ctypes.c_int32 * 5
+_i6 = ctypes.c_int32 * 6
 
 
 AUX_OUTPUTS = ("weights", "depth", "sigma", "colour", "sky_blended", "nosky")
@@ -32,8 +32,29 @@ class Window:
         """The H0 x W0 frame without its outer o rows / columns."""
         return cls(H0 * W0, W0, o * W0 + o, H0 - 2 * o, W0 - 2 * o)
 
-    def host(self, ray0=0):
-        return _i5(self.n_src, self.pitch, self.first, self.cols, int(ray0))
+    def blocked(self, ray0=0, n_rays=None):
+        """Whether a launch over this window orders its rays in 8 x 4 pixel blocks (csrc/field.hip RayWindow): the launch is the
+        whole window, of 8k columns x 4m rows.  SDN_RAY_BLOCKS=0 keeps the row-major order (A/B)."""
+        if not self.cols or ray0 or (n_rays is not None and n_rays != self.n_rays) or os.environ.get("SDN_RAY_BLOCKS", "1") in ("0", ""):
+            return False
+        rows = self.n_rays // self.cols
+        return self.cols % 8 == 0 and rows % 4 == 0 and rows * self.cols == self.n_rays
+
+    def groups(self, per_ray):
+        """per_ray [n_rays, ...] (window row-major) -> [n_groups, 32, ...]: the rays of every 32-ray group of a whole-window launch
+        in the launch's ray order (padding rays: zeros)."""
+        n = self.n_rays
+        if self.blocked(0, n):
+            rows = n // self.cols
+            v = per_ray.reshape(rows // 4, 4, self.cols // 8, 8, *per_ray.shape[1:])
+            return v.transpose(1, 2).reshape(-1, 32, *per_ray.shape[1:])
+        pad = (-n) % 32
+        if pad:
+            per_ray = torch.cat([per_ray, per_ray.new_zeros((pad,) + tuple(per_ray.shape[1:]))], dim=0)
+        return per_ray.reshape(-1, 32, *per_ray.shape[1:])
+
+    def host(self, ray0=0, n_rays=None):
+        return _i6(self.n_src, self.pitch, self.first, self.cols, int(ray0), 1 if self.blocked(ray0, n_rays) else 0)
 
 
 def _lib():
@@ -166,7 +187,7 @@ def encode(R, vid, d2, rd, cam_ori, ns, buf=None, u=None, window=None, ray0=0, n
                                      lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M, ns,
                                      R.sample_depth, R.dists_scale,
                                      buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
-                                     buf["rayflag"].data_ptr(), window.host(ray0), {"reciprocal": 0, "ieee": 1}[division],
+                                     buf["rayflag"].data_ptr(), window.host(ray0, n_rays), {"reciprocal": 0, "ieee": 1}[division],
                                      _stream(R.dev))
     capi.check(rc, "sdn_field_encode")
     return buf
@@ -222,7 +243,7 @@ def _launch_mlp(R, buf, st, sky_c, sky_avg, net_out, n_rays, ns, passes=None, wi
         rc = _lib().sdn_field_mlp(buf["feat"].data_ptr(), buf["dist"].data_ptr(), buf["label"].data_ptr(),
                                   buf["rayflag"].data_ptr(), st["packed_mx" if ct == 6 else "packed"].data_ptr(),
                                   st["consts"].data_ptr(), sky_c.data_ptr(), net_out.data_ptr(), n_rays, ns, ct, eps,
-                                  passes.data_ptr() if passes is not None else None, 0, window.host(ray0),
+                                  passes.data_ptr() if passes is not None else None, 0, window.host(ray0, n_rays),
                                   sky_avg.data_ptr(), st["ticket"].data_ptr() if dynamic else None, _stream(R.dev))
     capi.check(rc, "sdn_field_mlp")
 
@@ -333,7 +354,7 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
                                      sc["dims"].ctypes.data, lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M,
                                      ns, R.sample_depth, R.dists_scale, st["packed_mx" if ct == 6 else "packed"].data_ptr(),
                                      st["consts"].data_ptr(), p_sky, sky_avg.data_ptr(), net_out.data_ptr(), ct, eps,
-                                     passes.data_ptr() if passes is not None else None, 0, window.host(0),
+                                     passes.data_ptr() if passes is not None else None, 0, window.host(0, n_rays),
                                      {"reciprocal": 0, "ieee": 1}[division], st["ticket"].data_ptr(),
                                      ori_dev.data_ptr() if ori_dev is not None else None,
                                      ctypes.byref(aux_c) if aux_c is not None else None, _stream(R.dev))

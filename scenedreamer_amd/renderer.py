@@ -565,7 +565,7 @@ class Renderer:
                 vid, d2, rd, (H0, W0) = self.cast_rays(pose, resolution_hw)
                 hit = (vid.view(H0, W0, self.M)[o:H0 - o, o:W0 - o, 0] != 0).reshape(-1)
                 n = hit.numel()
-                g = torch.nn.functional.pad(hit, (0, (-n) % 32)).view(-1, 32).any(dim=1)
+                g = fused.Window.crop(H0, W0, o).groups(hit).any(dim=1)          # the 32-ray groups as the launch forms them
                 B += n * num_samples
                 hits += float(hit.float().mean())
                 groups += float(g.float().mean())

@@ -293,11 +293,13 @@ def test_sky_mean_finished_in_kernel(renderer):
         assert torch.equal(avg, avg2) and torch.equal(sky_c, sky_c2)
 
 
-def test_ray_window_equals_sliced_copies(renderer):
+def test_ray_window_equals_sliced_copies(renderer, monkeypatch):
     """encode / mlp reading the frame-wide ray arrays through a window (cropped apron, chunk offsets) produce the bits
     the same kernels produce on strided-slice COPIES of those rays; the dynamic group schedule (ticket counter)
-    produces the bits of the static one."""
+    produces the bits of the static one.  (Row-major ray order: the copies have no window to take the blocked order from;
+    test_blocked_ray_order_changes_no_bit covers that.)"""
     from scenedreamer_amd import fused
+    monkeypatch.setenv("SDN_RAY_BLOCKS", "0")
     renderer.set_style_code(golden("field_a.npz")["z"])
     pose, vid, d2, rd, H0, W0 = _frame(renderer)
     ns, o, M = 12, 11, renderer.M
@@ -339,6 +341,55 @@ def test_ray_window_equals_sliced_copies(renderer):
     finally:
         fused.FEATURE_BUFFER_BYTES = old
     assert torch.equal(chunked, whole)
+
+
+def test_blocked_ray_order_changes_no_bit(renderer, monkeypatch):
+    """A whole-window launch of 8k columns x 4m rows takes its rays in 8 x 4 pixel blocks (RayWindow::pix, include/sdnative.h
+    `window_host[5]`), so that the 32 rays of a group are neighbours in both directions.  Rays are independent: with every sample
+    evaluated (term_eps = 0) net_out is the same bits as in row-major order -- one-kernel and two-kernel field, deterministic and
+    stochastic sampling (u stays indexed by the pixel), the per-sample outputs -- and with early termination the two forms of
+    the field still agree with each other bit for bit; a window that is not whole blocks stays row-major."""
+    from scenedreamer_amd import fused
+    renderer.set_style_code(golden("field_a.npz")["z"])
+    pose, vid, d2, rd, H0, W0 = _frame(renderer)
+    ns = 12
+    ori = torch.as_tensor(pose[0], dtype=torch.float32)
+    with torch.no_grad():
+        sky_c, sky_avg = fused.sky_fused(renderer, rd)
+        win = fused.Window.crop(H0, W0, 11)
+        assert win.blocked(0, win.n_rays) and not fused.Window.crop(H0, W0, 10).blocked(0) and not win.blocked(32, win.n_rays - 32)
+        torch.manual_seed(7)
+        u = torch.rand(win.n_rays, ns + 1, device="cuda")
+        try:
+            outs = {}
+            for blocks in ("0", "1"):
+                monkeypatch.setenv("SDN_RAY_BLOCKS", blocks)
+                for one in (True, False):
+                    renderer.field_single_kernel = one
+                    renderer.set_precision(term_eps=0.0)
+                    a = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win)
+                    b = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win, u=u)
+                    renderer.set_precision(term_eps=0.05)
+                    pa = torch.zeros((win.n_rays + 31) // 32, dtype=torch.uint8, device="cuda")
+                    c = fused.field_fused(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win, passes=pa)
+                    outs[(blocks, one)] = (a, b, c, pa)
+                renderer.set_precision(term_eps=0.0)
+                aux = {"weights": None, "sigma": None, "nosky": None}
+                fused.field_render(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win, aux=aux)
+                outs[(blocks, "aux")] = aux
+            for k in (0, 1):        # every sample evaluated: the same bits whatever the order and the form
+                ref = outs[("0", True)][k]
+                assert all(torch.equal(outs[(bl, one)][k], ref) for bl in ("0", "1") for one in (True, False)), k
+            for bl in ("0", "1"):   # early termination: the two forms of the field agree under either order
+                assert torch.equal(outs[(bl, True)][2], outs[(bl, False)][2]) and torch.equal(outs[(bl, True)][3], outs[(bl, False)][3])
+            d = float((outs[("1", True)][2] - outs[("0", True)][2]).abs().max())
+            assert d <= 2 * 0.05 + 1e-6                                                # different groups stop: inside the termination bound
+            for k in ("weights", "sigma", "nosky"):
+                assert torch.equal(outs[("0", "aux")][k], outs[("1", "aux")][k]), k
+            assert not torch.equal(outs[("0", True)][0], outs[("0", True)][1])
+        finally:
+            renderer.field_single_kernel = None
+            renderer.set_precision()
 
 
 # ---------------------------------------------------------------------------------------------------- MX fp6 colour layers
