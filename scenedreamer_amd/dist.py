@@ -217,7 +217,9 @@ def balanced_row_bands(costs, world, min_rows=MIN_BAND_ROWS):
     """Contiguous output-row bands of equal COST: costs[r] >= 0 is the relative work of output row r (Renderer.row_costs: the
     field kernel only visits rays that hit something, so sky rows are nearly free and equal-height bands leave the ground bands
     bounding the frame).  Boundary k is the first row where the running cost reaches k / world of the total; every band keeps at
-    least min_rows rows.  Deterministic in `costs`: ranks that computed the same costs cut the same bands."""
+    least min_rows rows.  Deterministic in `costs`: ranks that computed the same costs cut the same bands.
+    Boundaries fall on multiples of 4 rows (when the height is one): a band's field launch then covers whole 8 x 4 pixel blocks
+    (with the 4-px apron on both sides) and takes the blocked ray order (csrc/field.hip RayWindow) like a full frame."""
     costs = np.asarray(costs, dtype=np.float64)
     H = costs.shape[0]
     if world <= 1 or H < world * min_rows or not np.isfinite(costs).all() or costs.sum() <= 0:
@@ -226,6 +228,8 @@ def balanced_row_bands(costs, world, min_rows=MIN_BAND_ROWS):
     cuts = [0]
     for k in range(1, world):
         r = int(np.searchsorted(cum, cum[-1] * k / world, side="left")) + 1
+        if H % 4 == 0 and min_rows % 4 == 0:
+            r = int(round(r / 4.0)) * 4
         r = max(r, cuts[-1] + min_rows)
         r = min(r, H - (world - k) * min_rows)
         cuts.append(r)
