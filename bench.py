@@ -794,7 +794,9 @@ def main():
                 per[name] = {"avg_launch_ms": ms_k, "algorithmic_flop_per_pixel": fl, "achieved": Hc * Wc * fl / (ms_k * 1e-3) / 1e12,
                              "frac": Hc * Wc * fl / (ms_k * 1e-3) / 1e12 / 2500.0, "f16_products_per_algorithmic_product": t_k}
             roof_cnn["per_launch_alone"] = {"pixels": Hc * Wc, "unit": "TFLOP/s", "peak": 2500.0, "bound": "mfma", "kernels": per,
-                                            "timing": "HIP events between the launches, 5 repetitions, nothing else on the GPU"}
+                                            "timing": "HIP events between the launches, 5 repetitions, nothing else on the GPU; an event between two launches opens a "
+                                                      "gap of ~0.05 - 0.1 ms that is inside these figures (their sum exceeds `alone_ms`): the pure kernel "
+                                                      "durations are rocprof's, profiles/r05_kernel_stats.md"}
             n_sky = (hw[0] + 30) * (hw[1] + 30)
             from scenedreamer_amd import fused as _fused
             from scenedreamer_amd.renderer import _time_ms

@@ -25,6 +25,8 @@ def stub_writers():
 
     def imwrite(path, img, params=None):
         img = np.asarray(img)
+        if img.dtype != np.uint8:           # cv2.imwrite saturate-casts (the depth loop hands it float32 * 255)
+            img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
         Image.fromarray(img[..., ::-1] if img.shape[-1] == 3 else img[..., 0]).save(path)      # cv2 takes BGR
         return True
 
