@@ -444,62 +444,3 @@ def test_unmodified_loop_at_the_headline_config_against_oracle_tiles(weights_ful
         json.dump({"config": "960x540x24, scene 2048, unmodified inference_givenstyle on install_shims(fast=True), tile_size 128, frame evaluated once "
                              "for its 40 tiles; last of 3 frames", "tiles": [list(t) for t in tiles], "max_abs_err": worst}, f)
     assert worst < TOL
-
-
-@pytest.mark.needs_reference
-def test_unmodified_depth_loop_on_the_fused_kernels(scene256, weights_full, tmp_path, monkeypatch):
-    """Generator.inference_givenstyle_depth (scenedreamer.py:636-851), UNCHANGED, on install_shims(fast=True) with
-    binding(G, aux=True): the loop reads `weights` and `rand_depth` of _forward_perpix's 12-tuple per tile (:812-817,
-    depth_map = sum(weights * rand_depth)) -- the field kernel's MODE_FUSED_AUX instantiation writes them.  Its RGB frames equal
-    inference_givenstyle's on the same trajectory to one uint8 level, the depth images are written, not constant, and agree with
-    a depth map recomposed from the reference's own _forward_perpix outputs.  (`np.float`, which the method still uses, is gone
-    from this image's numpy: restored for the call -- an environment matter, like the cv2 / imageio stand-ins.)"""
-    from PIL import Image
-    from loop_helpers import run_reference_loop, stub_writers
-    from scenedreamer_amd import dropin, synth
-    G, _ = _generator(weights_full, scene256, fast=True, aux=True)
-    hw, ns, steps, tile = [72, 104], 12, 2, 64
-    b = dropin.binding(G)
-    monkeypatch.setattr(np, "float", float, raising=False)
-    frames, undo = stub_writers()
-    style = torch.from_numpy(np.asarray(synth.make_style(8888))).cuda()
-    out_dir = str(tmp_path / "depth")
-    try:
-        with torch.no_grad():
-            G.inference_givenstyle_depth(style, out_dir, camera_mode=0, num_samples=ns, tile_size=tile, resolution_hw=list(hw), cam_ang=72,
-                                         cam_maxstep=steps)
-    finally:
-        undo()
-    assert b.stats["perpix_fast"] == steps * 4 and b.stats["perpix_reference"] == 0 and b.stats["global_fast"] == steps * 4, b.stats
-    rgb = [f for f in frames if f.shape == (hw[0], hw[1], 3)]                    # (the second writer gets mask | rgb side by side)
-    assert len(rgb) == steps and len(frames) == 2 * steps
-    depth = [np.asarray(Image.open(os.path.join(out_dir, "depth", f"{i:05d}.png"))).astype(np.int32) for i in range(steps)]
-    assert all(d.shape[:2] == (hw[0], hw[1]) and d.std() > 3 for d in depth)
-    # the plain loop on the same trajectory (net_out only): the same pictures
-    b.aux = False
-    plain = run_reference_loop(G, str(tmp_path / "plain"), hw, ns, steps, tile_size=tile)
-    for a, c in zip(rgb, plain):
-        assert np.abs(a.astype(np.int32) - c.astype(np.int32)).max() <= 1
-    # the depth map of the last frame from the REFERENCE's own _forward_perpix (on the HIP ops), normalised as the loop does (:833-841)
-    import sys
-    voxlib = sys.modules["voxlib"]
-    from scenedreamer_amd import camera
-    pose = camera.eval_camera_poses(scene256, maxstep=steps, pattern=0, cam_ang=72)[steps - 1]
-    with torch.no_grad():
-        vid, d2, rd = voxlib.ray_voxel_intersection_perspective(G.voxel.voxel_t, pose[0], pose[1], pose[2], pose[3] * (hw[1] - 1),
-                                                                [(G.cam_res[0] - 1) / 2, (G.cam_res[1] - 1) / 2], G.cam_res, 6)
-        vid, d2, rd = vid.unsqueeze(0), d2.unsqueeze(0), rd.unsqueeze(0)
-        z = G.style_net(style)
-        ge = G.world_encoder(G.voxel.current_height_map, G.voxel.current_semantic_map)
-        out = G._forward_perpix_reference(None, vid, d2.clone(), rd, pose[0][None].cuda(), z, ge)
-        dm = torch.sum(out[2] * out[4], -2).permute(0, 3, 1, 2)[:, :, 15:-15, 15:-15]
-        m = dm > 0
-        t = dm[m]
-        dm[~m] = 1
-        dm[m] = (t - t.min()) / (t.max() - t.min())
-        ref = np.clip(np.rint(dm[0, 0].cpu().numpy() * 255), 0, 255).astype(np.int32)
-    got = depth[-1] if depth[-1].ndim == 2 else depth[-1][..., 0]
-    diff = np.abs(got - ref)
-    print(f"inference_givenstyle_depth (unmodified, fast shims, aux): depth PNG vs the reference method's depth map: max |diff| {diff.max()} levels, "
-          f"{100 * (diff > 1).mean():.2f} % of the pixels differ by more than one level")
-    assert (diff > 2).mean() < 0.01
