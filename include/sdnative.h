@@ -143,7 +143,8 @@ int sdn_grid_encode_fwd(const float *inputs, const void *embeddings, int emb_dty
  *   uses them (gridencoder.cu:126-127), evaluated on the host; resolutions_host may be NULL              */
 int sdn_grid_level_scales(uint32_t L, float S, uint32_t H, float *scales_host, uint32_t *resolutions_host);
 /*   grad [L,B,C]; grad_embeddings [sO,C] pre-zeroed by the caller (accumulated with atomics);
- *   grad_inputs [B,D] written when calc_grad_inputs.  F32 only in this release.          */
+ *   grad_inputs [B,D] written when calc_grad_inputs.  emb_dtype SDN_F32 or SDN_F16 (grad and grad_embeddings in that type:
+ *   __half2 atomics for f16, as gridencoder.cu:227-343 does).                                                            */
 int sdn_grid_encode_bwd(const void *grad, const float *inputs, const void *embeddings, int emb_dtype,
                         const int32_t *offsets, void *grad_embeddings, uint32_t B, uint32_t D, uint32_t C,
                         uint32_t L, float S, uint32_t H, int calc_grad_inputs, const void *dy_dx,

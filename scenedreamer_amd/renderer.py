@@ -282,7 +282,22 @@ class Renderer:
         self.sky_terms_auto = None
 
     # ------------------------------------------------------------------ per-style precision gates
-    def calibrate_style(self, pose, resolution_hw, num_samples):
+    def calibrate_style(self, pose, resolution_hw, num_samples, more_poses=()):
+        """calibrate_one on `pose` and on every pose of `more_poses` (the trajectory loop adds the middle pose of the trajectory:
+        the errors depend on what the camera sees), the measurements combined with MAX, then adopt_precision -- the decision a
+        multi-rank job reaches by reducing the same measurements over its ranks (dist.agree_precision)."""
+        meas = self.calibrate_one(pose, resolution_hw, num_samples)
+        for p2 in more_poses:
+            m2 = self.calibrate_one(p2, resolution_hw, num_samples)
+            for k, v in m2.items():
+                if isinstance(v, dict):
+                    meas[k] = {kk: max(vv, meas[k].get(kk, vv)) if isinstance(vv, float) else vv for kk, vv in v.items()}
+                elif isinstance(v, float):
+                    meas[k] = max(v, meas.get(k, v))
+            meas["poses"] = meas.get("poses", 1) + 1
+        return self.adopt_precision(meas)
+
+    def calibrate_one(self, pose, resolution_hw, num_samples):
         """Measure END TO END, for the CURRENT weights and style, what the reduced-precision choices of the fused path cost, and
         decide.  One frame (`pose`; at most CAL_MAX_PIXELS pixels -- a larger frame is calibrated at a reduced resolution) is
         rendered by the reference's op sequence in fp32 (field_unfused + render_cnn: PyTorch fp32 + the drop-in HIP ops -- the
@@ -301,7 +316,8 @@ class Renderer:
         The errors depend on the loaded weights (the density head amplifies hidden-activation error; 3x3 gains compound over
         four layers): tests/test_precision_gates_gpu.py scales them until every gate closes.  Explicit settings (set_precision,
         SDN_MLP_COLOUR_TERMS, SDN_CNN_TERMS) are measured but not overridden.  Costs one fp32 frame (~0.2 s at 960x540x24) per
-        style.  Records: `field_gate`, `cnn_calibration` (bench.py prints both)."""
+        pose.  Returns the measurements; calibrate_style turns them into the records `field_gate`, `cnn_calibration` (bench.py
+        prints both)."""
         from . import fused
         H, W = resolution_hw
         if H * W > CAL_MAX_PIXELS:
@@ -368,7 +384,7 @@ class Renderer:
                 meas["cnn_diff"] = meas["cnn_diffs"][1]
         meas.update(explicit_colour=explicit_ct, explicit_cnn=explicit_t, pixels=int(H * W), rays=int(n), samples_per_ray=int(num_samples),
                     frame=f"{W}x{H} (+{self.pad}-px apron), {num_samples} samples/ray")
-        return self.adopt_precision(meas)
+        return meas
 
     def adopt_precision(self, meas):
         """Decisions that follow from calibrate_style's measurements (a pure function of `meas`: dist.agree_precision reduces the
@@ -860,7 +876,7 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
         side = self._side_stream = torch.cuda.Stream(self.dev)
     if mode == "fused":
         if getattr(self, "field_gate", None) is None and FIELD_GATE:
-            self.calibrate_style(poses[0], resolution_hw, num_samples)
+            self.calibrate_style(poses[0], resolution_hw, num_samples, more_poses=poses[len(poses) // 2:len(poses) // 2 + 1] if len(poses) > 2 else ())
         if self.field_falls_back():
             mode = "unfused"
     f0, c0, cam_res = frame_intrinsics(poses[0][3], resolution_hw, self.pad)
@@ -1008,7 +1024,7 @@ FIELD_AUTO_BOUND = 1e-3    # largest net_out error of the fused field vs the fp3
                            # fp64 evaluation as PyTorch's fp32 one is (1e-4 both).
 IMAGE_AUTO_BOUND = 8e-4    # largest image error of the whole fused path vs the fp32 path, whole frame
 SKY_AUTO_BOUND = 2e-4      # largest sky_c error (vs PyTorch fp32) at which the sky MLP's hidden layers run as f16 + fp6 corrections
-CAL_MAX_PIXELS = 1 << 20   # frames above this many pixels are calibrated at a reduced resolution (same pose)
+CAL_MAX_PIXELS = 1 << 22   # frames above this many pixels (1920x1080 is below: calibrated at its own resolution) are calibrated at a reduced resolution (same pose)
 CAL_CHUNK = 1 << 16        # rays per launch group of the fp32 field
 MISS_COST = 0.2            # row_costs: cost of a ray that hits nothing relative to one that does (ray casting + sky MLP + CNN vs + field)
 FIELD_GATE = os.environ.get("SDN_FIELD_GATE", "1") != "0"   # (0: no field calibration -- kernel timing experiments only)
