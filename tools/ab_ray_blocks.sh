@@ -1,5 +1,7 @@
 #!/bin/bash
-# blocked ray order (8 x 4 pixel groups): tests + same-box A/B on the headline bench
+# same-box A/B of environment switches of the field kernel on the headline bench (tools/gpu_session.sh <label> ab_ray_blocks):
+#   SDN_RAY_BLOCKS=0|1 (row-major vs 8 x 4-pixel ray groups), preceded by the tests that pin both orders to the same bits;
+#   SDN_COLOUR_SKIP=0|1 works the same way (profiles/r05_ab_colour_skip.txt was taken like this)
 label=$1
 export TMPDIR=/tmp
 echo "--- tests"; timeout 1500 python -m pytest tests/test_fused_gpu.py tests/test_render_gpu.py tests/test_fullsize_gpu.py tests/test_dist_gpu.py tests/test_dropin_gpu.py -q -m gpu > gpurun_out/${label}_tests.log 2>&1; tail -4 gpurun_out/${label}_tests.log
