@@ -656,6 +656,10 @@ class Renderer:
                "samples_with_colour_branch": n_col, "colour_branch_flop_per_sample": 294912, "algorithmic_flop_per_launch": flop_launch,
                "colour_passes_skipped_fraction": 1.0 - n_col / max(n_eval, 1.0),
                "achieved_counting_skipped_colour_branch": n_eval * 754176 / (ms_mlp * 1e-3) / 1e12,
+               "frac_counting_skipped_colour_branch": n_eval * 754176 / (ms_mlp * 1e-3) / 1e12 / mfma_peak_tflops,
+               "accounting": "`achieved` / `frac` count the FLOPs the launch EXECUTES; `*_counting_skipped_colour_branch` is SURVEY 8(d)'s "
+                             "754 176 FLOP x every sample the launch finishes (a skipped colour branch is a finished sample: its colour is "
+                             "multiplied by a weight that is exactly zero) -- the figure comparable with earlier rounds' `frac`",
                "avg_launch_ms": ms_mlp, "ray_hit_fraction": hit, "group_hit_fraction": ev["group_hit_fraction"],
                "early_termination_eps": eps, "passes_skipped_by_termination": ev["passes_skipped_by_termination"],
                "issued_over_algorithmic": issued, "issued_frac_of_peak": ach_m * issued / mfma_peak_tflops,
