@@ -376,6 +376,11 @@ def dropin_record(args, weights, scene, dev, oracle_tiles=None):
         except Exception as ex:  # noqa: BLE001 -- an extra figure must not cost the record
             out["max_abs_diff_vs_renderer"] = f"not measured ({type(ex).__name__}: {ex})"
     out["cnn_gate"] = b.B.cnn_calibration
+    try:
+        from scenedreamer_amd import modules as _modules
+        out["sky_gate"] = getattr(_modules._backend(G.sky_net), "sky_gate", None)
+    except Exception:  # noqa: BLE001
+        out["sky_gate"] = None
     del G
     torch.cuda.empty_cache()
     return out

@@ -24,6 +24,7 @@ Two ways in:
   * the stand-alone classes below, for use without the reference's Python tree.
 """
 import itertools
+import os
 
 import numpy as np
 import torch
@@ -240,6 +241,21 @@ class SKYMLPNative:
                     # since): the kernel evaluates the encoding itself, and the per-ray result is kept for
                     # Generator._forward_perpix, which asks for sky_net of the very same rays again for every tile
                     # (scenedreamer.py:368-370 after the frame-wide pre-pass :592-598)
+                    # The renderer's per-style sky gate (Renderer.calibrate_style) for this surface: on the first frame of a style the
+                    # hidden layers are evaluated as f16 + fp6 corrections AND as the 3-term split (4e-6 from fp32); the cheap form is
+                    # kept for the style if the two stay within SKY_AUTO_BOUND of each other.  One extra launch per style.
+                    gate_key = (B._zkey.get("sky_net."), B._bound["sky_net."][1])
+                    if getattr(B, "_sky_gate_key", None) != gate_key and "SDN_SKY_TERMS" not in os.environ and getattr(B, "sky_terms", None) is None:
+                        from .renderer import SKY_AUTO_BOUND
+                        B.sky_terms_auto = None
+                        c3, _ = fused.sky_fused(B, rd)
+                        B.sky_terms_auto = 6
+                        c6, _ = fused.sky_fused(B, rd)
+                        d = float((c6 - c3).abs().max())
+                        if not d <= SKY_AUTO_BOUND:
+                            B.sky_terms_auto = None
+                        B._sky_gate_key = gate_key
+                        B.sky_gate = {"hidden_terms": 6 if B.sky_terms_auto == 6 else 3, "max_abs_diff_fp6_vs_3term": d, "bound": SKY_AUTO_BOUND}
                     sky_c, _ = fused.sky_fused(B, rd)
                     # (rd_ref keeps the ray-direction storage alive: while this record exists its address cannot be handed to
                     #  another tensor, so "same address + same version counter" below means "same content")
