@@ -1754,6 +1754,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     };
     int vox_cur = 0;
     if constexpr (FUSED) vox_cur = first_vox(grp);
+    int cold = 0;     // (uniform) consecutive groups of this workgroup that were found dense, or not asked (colour-branch skipping)
     while (grp < n_groups) {
         const int tile = grp * 4 + wave;
         const bool tile_ok = tile < p.n_tiles;
@@ -1790,7 +1791,12 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         float outq[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         float carry = 0.f, tsum = 0.f;
         int n_done = 0, n_colour = 0;
-        bool skip_test = SKIP && !p.no_colour_skip;     // (uniform) whether the next pass of this group takes the colour-skip decision at all
+        // (uniform) whether the next pass of this group takes the colour-skip decision at all.  Across groups: after 6 groups in a row
+        // whose first pass was less than 1/4 empty (a field with surfaces: rays saturate, nothing is empty) only every 4th group
+        // still decides -- there the early sigma was +1 % of the frame for nothing (tools/bench_opaque.py); on the benchmark
+        // frames the rule costs about one point of skipped passes (dense stretches end somewhere)
+        bool skip_test = SKIP && !p.no_colour_skip && (cold < 6 || (cold & 3) == 0);
+        if (SKIP && !skip_test) cold++;
 
         for (int ch = 0; grp_hit && ch < p.nch; ch++) {
             const size_t tc = (size_t)(tile_ok ? tile : 0) * p.nch + ch;
@@ -1966,6 +1972,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                         //  barriers and its share of the ring DMA only.  Same box: 15.03 -> 15.55 ms, 18.49 -> 19.08 ms: the idle
                         //  SIMD buys the other three nothing, the extra decisions cost.  Not kept.)
                         skip_test = grp_zero >= 192;
+                        if (ch == 0) cold = grp_zero < 64 ? cold + 1 : 0;
                         if (grp_zero == 256) { colour_skipped = true; break; }
                     }
                 }
