@@ -462,3 +462,45 @@ def test_f16_split_loses_bits_to_subnormals_unless_the_weights_are_scaled():
     rng = np.random.default_rng(0); scaled = run(8)
     assert plain > 4 * scaled, (plain, scaled)          # measured: 1.1e-6 vs 1.3e-7
     assert scaled < 3e-7                                 # below what fp32 operands give (4.6e-7)
+
+
+def test_blocked_ray_order_host_side():
+    """fused.Window: when a launch takes its rays in 8 x 4 pixel blocks (csrc/field.hip RayWindow::pix, `window_host[5]`) and how the
+    host regroups per-ray data into the launch's 32-ray groups -- against the kernel's index formula restated here."""
+    import torch
+    from scenedreamer_amd import fused
+    H0, W0, o = 102, 134, 11
+    win = fused.Window.crop(H0, W0, o)
+    rows, cols = H0 - 2 * o, W0 - 2 * o
+    assert (rows, cols) == (80, 112) and win.blocked(0, win.n_rays) and list(win.host(0, win.n_rays))[5] == 1
+    assert not win.blocked(32, win.n_rays - 32) and list(win.host(32, win.n_rays - 32))[5] == 0          # a chunk: row-major
+    assert not fused.Window.crop(H0, W0, 10).blocked(0)                                                  # 82 x 114: not whole blocks
+    assert not fused.Window(1000).blocked(0) and list(fused.Window(1000).host())[3:] == [0, 0, 0]        # no window at all
+    bx = cols // 8
+
+    def pix(r):          # RayWindow::pix, tiled_bx = cols / 8, ray0 = 0
+        b, within = r >> 5, r & 31
+        by, bxi = divmod(b, bx)
+        return (4 * by + (within >> 3)) * cols + 8 * bxi + (within & 7)
+    per_ray = torch.arange(win.n_rays)
+    g = win.groups(per_ray)
+    assert tuple(g.shape) == (win.n_rays // 32, 32)
+    want = torch.tensor([pix(r) for r in range(win.n_rays)]).view(-1, 32)
+    assert torch.equal(g, want) and sorted(g.reshape(-1).tolist()) == list(range(win.n_rays))         # a permutation of the window's pixels
+    # every group is an 8-wide, 4-high block of the window
+    y, x = g // cols, g % cols
+    assert bool(((y.max(1).values - y.min(1).values) == 3).all()) and bool(((x.max(1).values - x.min(1).values) == 7).all())
+    # source rays: first + y * pitch + x
+    src = win.first + y * win.pitch + x
+    assert int(src.min()) == o * W0 + o and int(src.max()) == (H0 - o - 1) * W0 + (W0 - o - 1)
+    os.environ["SDN_RAY_BLOCKS"] = "0"
+    try:
+        assert not win.blocked(0, win.n_rays) and torch.equal(win.groups(per_ray), per_ray.view(-1, 32))
+    finally:
+        del os.environ["SDN_RAY_BLOCKS"]
+    # balanced bands fall on multiples of 4 rows, so a band (+ 2 x 4 apron rows, width + 8) is whole blocks too
+    from scenedreamer_amd import dist as sdist
+    costs = np.r_[np.full(700, 0.2), np.linspace(0.2, 3.0, 800), np.full(660, 3.0)]
+    bands = sdist.balanced_row_bands(costs, 8)
+    assert all(b[0] % 4 == 0 for b in bands) and bands[-1][1] == 2160
+    assert all(fused.Window((b[1] - b[0] + 30) * 3870, 3870, 11 * 3870 + 11, b[1] - b[0] + 8, 3848).blocked(0) for b in bands)
