@@ -148,3 +148,51 @@ def test_balanced_row_bands():
     tail = sdist.balanced_row_bands(np.r_[np.zeros(90), np.ones(10)], 4)
     assert all(b - a >= sdist.MIN_BAND_ROWS for a, b in tail) and tail[-1][1] == 100
     assert sdist.balanced_row_bands(np.ones(540), 1) == [(0, 540)]
+
+
+def _agree_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from scenedreamer_amd import dist as sdist
+        from scenedreamer_amd import renderer as rmod
+
+        R = object.__new__(rmod.Renderer)          # adopt_precision is a pure function of the measurements
+        R.dev = torch.device("cpu")
+        R._fused_style = None
+
+        def calibrate_style(pose, hw, ns):
+            # what two ranks could measure on their frames: rank 1 sees the rung "1113" just outside the gate, rank 0 inside
+            d1113 = 4.5e-4 if rank == 0 else 5.5e-4
+            meas = dict(field_err={6: 6e-5 + 1e-5 * rank, 3: 5e-5}, colour_diff=5e-5, sky_err={3: 4e-6, 6: 1e-4},
+                        image_err={1: 7e-4, "1113": d1113 + 1e-5, "1133": 3.5e-4, 3: 5e-5}, cnn_diff=6e-4,
+                        cnn_diffs={1: 6e-4, "1113": d1113, "1133": 3.4e-4}, explicit_colour=None, explicit_cnn=None, explicit_sky=None,
+                        pixels=518400, rays=564300, samples_per_ray=24, frame="t")
+            return R.adopt_precision(meas)
+        R.calibrate_style = calibrate_style
+        own = calibrate_style(None, None, None)
+        own_rung = R.cnn_calibration["terms3x3"]
+        got = sdist.agree_precision(R, None, (540, 960), 24)
+        q.put((rank, own_rung, got["cnn"]["terms3x3"], got["cnn"]["max_abs_diff_vs_3term"]["1113"], got["field"]["max_abs_err_vs_fp32"],
+               got["cnn"].get("agreed_over_ranks")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_precision_ladder_is_agreed_over_ranks_world2():
+    """dist.agree_precision with the CNN ladder: every rank measures every rung (mixed int / str keys), the measurements are reduced
+    with MAX, and all ranks adopt the same rung -- the one the WORST rank's measurements allow."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == ["1113", "1133"]                 # left alone, the ranks would have rendered with different precisions
+    assert [r[2] for r in res] == ["1133", "1133"]                 # agreed: the rung the worst measurement allows
+    assert all(abs(r[3] - 5.5e-4) < 1e-12 and abs(r[4] - 7e-5) < 1e-12 and r[5] == 2 for r in res)
