@@ -24,6 +24,36 @@ def test_field_ref_reproduces_reference_golden(oracle, weights_full, scene256, l
         np.testing.assert_allclose(img.numpy(), g["image"], rtol=0, atol=1e-6)
 
 
+def test_zero_weight_samples_do_not_reach_net_out(oracle, weights_full, scene256, lut):
+    """The property field_kernel's colour-branch skipping rests on, stated on the reference's own arithmetic (the oracle's
+    restatement of mc_utils.py:154-161 and scenedreamer.py:373-413): a sample with relu(sigma) * dist == 0 gets volume-rendering
+    weight EXACTLY 0.0, so net_out is the same bits whatever its colour is -- the kernel may leave fc_5 / fc_6 / fc_out_c out for
+    a pass made of such samples only.  Checked on the goldens' inputs: the weights are exact zeros there, and recompositing with
+    those samples' colours replaced (by huge values, by zero) reproduces net_out bit for bit."""
+    from oracle import field_ref as FR
+    seen = 0
+    for tag in "abc":
+        g = golden(f"field_{tag}.npz")
+        no, aux = FR.forward_perpix(weights_full, lut, scene256.voxel_t.shape, g["voxel_id"], g["depth2"], g["raydirs"],
+                                    g["cam_ori"][None], g["z"], g["global_enc"], int(g["num_samples"]),
+                                    sky_avg=g["sky_avg"], return_aux=True)
+        sigma, dists, wts, col, sky = aux["sigma"], aux["new_dists"] * 0.25, aux["weights"], aux["color"], aux["sky"]
+        empty = (torch.relu(sigma) * dists) == 0
+        assert bool((wts[empty] == 0).all()) and bool(empty.any()) and not bool(empty.all())
+        seen += int(empty.sum())
+
+        def composite(colour):        # scenedreamer.py:407-413 on the oracle's per-sample outputs
+            rgbs = torch.clamp(colour, -1, 1) + 1
+            rgbs_sky = torch.clamp(sky, -1, 1) + 1
+            return (torch.sum(wts * rgbs, dim=-2, keepdim=True) + (1.0 - torch.sum(wts, dim=-2, keepdim=True)) * rgbs_sky).squeeze(-2) - 1
+        base = composite(col)
+        np.testing.assert_array_equal(bits(base.numpy()), bits(no.numpy()))
+        for junk in (1e30, 0.0, -7.0):
+            other = torch.where(empty.expand_as(col), torch.full_like(col, junk), col)
+            np.testing.assert_array_equal(bits(composite(other).numpy()), bits(no.numpy()))
+    assert seen > 1000
+
+
 def test_sample_depth_oracle_reproduces_reference_golden():
     """oracle/field_ref.sample_depth_batched (deterministic and the training-time stochastic branch, fed with the stored
     torch.rand draw) == the unmodified mc_utils.sample_depth_batched (oracle/make_golden_sampling.py), bit for bit."""
