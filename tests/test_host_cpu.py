@@ -504,3 +504,55 @@ def test_blocked_ray_order_host_side():
     bands = sdist.balanced_row_bands(costs, 8)
     assert all(b[0] % 4 == 0 for b in bands) and bands[-1][1] == 2160
     assert all(fused.Window((b[1] - b[0] + 30) * 3870, 3870, 11 * 3870 + 11, b[1] - b[0] + 8, 3848).blocked(0) for b in bands)
+
+
+def test_weight_ring_protocol_with_restarts():
+    """A model of field_kernel's LDS weight ring (csrc/field.hip: Ring, ring_acquire, ring_restart): 4 positions, the DMA runs 3 slots
+    ahead, a pass streams 46 slots (fc_1: 4, fc_2..fc_6: 8 each, fc_out_c: 2) -- or only the first 28 when its colour branch is
+    skipped, after which ring_restart refills the three positions in flight with the NEXT pass's first slots.  Invariants checked over
+    random skip patterns: every acquire finds the slot it expects in its position; a refill never lands on the position of the slot
+    that is current or of the one consumed just before (which slower waves may still be reading); the restart leaves exactly the
+    state the kernel starts in."""
+    import random
+    NSLOT, AHEAD, PER_PASS, TRUNK = 4, 3, 46, 28
+    rng = random.Random(5)
+    for trial in range(20):
+        content = [None] * NSLOT          # (pass, slot in pass) whose weights a position holds
+        g, next_in_pass, issue_pass = 0, AHEAD, 0
+        for sl in range(AHEAD):
+            content[sl] = (0, sl)
+        last_consumed_pos = None
+        consumed = set()
+
+        def acquire(expect):
+            nonlocal g, next_in_pass, issue_pass, last_consumed_pos
+            pos = g % NSLOT
+            assert content[pos] == expect, (trial, expect, content, g)
+            dst = (g + AHEAD) % NSLOT                                   # refill of slot g + 3 goes where slot g - 1 was
+            assert dst == (g - 1) % NSLOT and dst != pos
+            assert content[dst] is None or content[dst] in consumed, (trial, content[dst])   # never over weights still to be used
+            consumed.add(expect)
+            content[dst] = (issue_pass, next_in_pass)
+            next_in_pass += 1
+            if next_in_pass == PER_PASS:
+                next_in_pass, issue_pass = 0, issue_pass + 1
+            last_consumed_pos = pos
+            g += 1
+
+        def restart(next_pass):
+            nonlocal next_in_pass, issue_pass
+            for sl in range(AHEAD):
+                dst = (g + sl) % NSLOT
+                assert dst != last_consumed_pos                        # the last slot of fc_4 may still be read by a slower wave
+                assert content[dst] is None or content[dst] in consumed or content[dst][0] == next_pass - 1   # stale slots of the skipped colour branch
+                content[dst] = (next_pass, sl)
+            next_in_pass, issue_pass = AHEAD, next_pass
+
+        for p in range(200):
+            skip = rng.random() < (0.0, 0.3, 0.6, 1.0)[trial % 4]
+            for sl in range(TRUNK if skip else PER_PASS):
+                acquire((p, sl))
+            if skip:
+                restart(p + 1)
+                # exactly the state a kernel start has, shifted by g: the next three positions hold slots 0, 1, 2 of the next pass
+                assert [content[(g + sl) % NSLOT] for sl in range(AHEAD)] == [(p + 1, sl) for sl in range(AHEAD)] and next_in_pass == AHEAD
