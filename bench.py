@@ -23,11 +23,14 @@ Other BASELINE.json configurations are one command each:
 `python -m torch.distributed.run --nproc-per-node N`; the world size must equal --gpus, and with the RCCL backend N GPUs
 must be visible -- anything else stops with an error instead of reporting a smaller job.
 
-Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` for the dominant kernel (the field MLP),
-`roofline_grid_sampler`, `roofline_cnn`, `roofline_rvip` and, at N=1, `cpu_baseline` (the reference / the CPU oracle timed on
-this box's host cores), `precision` (measured error + the per-style gates), `dropin` (the UNMODIFIED reference generator's
-inference_givenstyle loop on the fast shims, when the reference's Python tree is present) and `other_configs` (BASELINE
-configs 3 and 5 on this GPU: a few frames each + one oracle tile).  --only dropin|other prints just that record.
+Output: stdout carries exactly ONE line, the last one, <= 6 KB of JSON (scenedreamer_amd/benchline.py: `compact`): the driver
+contract's keys, numeric `roofline` (dominant kernel: the field MLP) / `roofline_grid_sampler` / `roofline_cnn` /
+`roofline_rvip` / `roofline_sky`, at N=1 `cpu_baseline` (the unmodified reference on this box's host cores) and `precision`,
+and one number each for the unmodified reference loop on the fast shims, configs 3 / 5 on this GPU, the fp32 rung, the
+no-skip floor (fog weights), colour skipping off, and the per-style one-off costs.  The FULL record (gates, per-tile
+errors, per-launch tables, the prose that explains each figure) is written to `bench_detail.json` next to this file (or
+$SDN_BENCH_DETAIL).  Everything else that would reach stdout (library chatter, the reference loop's own prints) is sent to
+stderr at file-descriptor level.  --only dropin|other prints just that record.
 """
 import argparse
 import json
@@ -211,6 +214,7 @@ def cpu_baseline(args, weights, scene, z, genc):
                       f"pre-pass of the whole padded frame + {len(picks)} (pose 8) and {len(picks_b)} (pose 26 of the 40-pose orbit) of the "
                       f"reference's {nh * nw} tiles per frame: {t_frame:.2f} s frame-wide + {t_tiles:.2f} s for {sampled} tile-rays in all, each "
                       f"pose extrapolated to its {frame_tile_rays} tile-rays; value = 2 frames / the two extrapolated frame times",
+            "sample_short": f"whole-frame ray cast + sky + {len(picks)}+{len(picks_b)} of {nh * nw} tiles/frame, poses 8, 26; extrapolated to a frame",
             "frames_per_s_by_pose": per_pose,
             "thread_calibration_s": {str(k): round(v, 3) for k, v in cal.items()}, "host_cpus": os.cpu_count(),
             "implementation": what}
@@ -487,6 +491,91 @@ def early_termination_record(args, R, weights, scene, poses, hw, mode):
     return rec
 
 
+def _trajectory_ms(Rx, sel, hw, ns, mode, apron, warm=2):
+    """ms per frame of the pipelined trajectory loop over `sel` (after `warm` untimed frames of the same loop)."""
+    for _ in Rx.render_frames(sel[:warm], hw, ns, mode=mode, apron=apron):
+        pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in Rx.render_frames(sel, hw, ns, mode=mode, apron=apron):
+        pass
+    torch.cuda.synchronize()
+    return 1000.0 * (time.perf_counter() - t0) / len(sel)
+
+
+def floor_record(args, R, weights, scene, poses, hw, mode):
+    """The regime in which the field kernel can remove NOTHING: `synth.fog_weights` (density 6 +- 0.65 at
+    every sample: no ray terminates, no sample has weight zero, all 24 colours of every hit ray are composited) on the DENSEST
+    pose of the orbit (most rays that hit), 8 frames of the pipelined loop.  The record also carries the style's calibration
+    (image error of the fused path against the fp32 op sequence on these weights) and the kernel's own pass counters, which
+    must show 0 terminated / 0 colour-skipped passes."""
+    from scenedreamer_amd import synth
+    from scenedreamer_amd.renderer import Renderer
+    with torch.no_grad():
+        hits = [float((R.cast_rays(p, hw)[0][..., 0] != 0).float().mean()) for p in poses]
+    dense = int(np.argmax(hits))
+    Rf = Renderer(synth.fog_weights(weights), scene, R.dev)
+    Rf.set_style_code(R.z)
+    sel = [poses[dense]] * 8
+    ms = _trajectory_ms(Rf, sel, hw, args.samples, mode, args.apron)
+    _, _, ev = Rf.field_work(sel[:1], hw, args.samples, args.apron)
+    ms_bench = _trajectory_ms(R, sel, hw, args.samples, mode, args.apron)      # the benchmark weights on the same pose
+    rec = {"frames_per_s": 1000.0 / ms, "ms_per_frame": ms, "pose": dense, "ray_hit_fraction": hits[dense],
+           "benchmark_weights_same_pose_frames_per_s": 1000.0 / ms_bench,
+           "passes_skipped_by_termination": ev["passes_skipped_by_termination"],
+           "colour_branch_skipped_fraction": 1.0 - ev["colour_samples"] / max(1.0, ev["evaluated_samples"]),
+           "evaluated_samples": ev["evaluated_samples"],
+           "max_abs_err_vs_fp32": (Rf.field_gate or {}).get("image_err_vs_fp32"), "net_out_err_vs_fp32": (Rf.field_gate or {}).get("max_abs_err_vs_fp32"),
+           "cnn_terms3x3": (Rf.cnn_calibration or {}).get("terms3x3"), "path": (Rf.field_gate or {}).get("path"),
+           "weights": "synth.fog_weights: fc_sigma x 0.03 + 6 (sigma > 0 everywhere, final transmittance > term_eps)"}
+    del Rf
+    return rec
+
+
+def style_cost_record(args, weights, scene, poses, hw, mode, dev):
+    """What a NEW style costs before and with its first frames, in a warm process: the reference calls
+    style_net once per inference_givenstyle and ships 40 frames per call (scenedreamer.py:570, configs/scenedreamer_inference.yaml).
+    trajectory40: set_style + the 40 poses of the orbit through render_frames, everything included (fold, weight packing,
+    calibration, frames), wall clock to the completion of the last frame; first_frame_ms: to the completion of frame 0.
+    A second fresh style gives the components: style_setup_ms (style MLP + fold + pack of field / sky / CNN weights),
+    calibration_ms (calibrate_style as the trajectory loop calls it)."""
+    from scenedreamer_amd import fused, synth
+    from scenedreamer_amd.renderer import Renderer
+    R2 = Renderer(weights, scene, dev)
+    fused.prepare_scene(R2)                 # per SCENE (collapsed table), not per style
+    R2.set_style(synth.make_style(8888))    # (warm-up style: this renderer's buffers, streams, CNN planes)
+    for _ in R2.render_frames(poses[:2], hw, args.samples, mode=mode, apron=args.apron):      # buffers / streams of this renderer
+        pass
+    torch.cuda.synchronize()
+    orbit = [poses[k % len(poses)] for k in range(40)]
+    t0 = time.perf_counter()
+    R2.set_style(synth.make_style(1111))
+    first = None
+    for k, im in enumerate(R2.render_frames(orbit, hw, args.samples, mode=mode, apron=args.apron)):
+        if k == 0:
+            torch.cuda.synchronize()
+            first = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    rec = {"trajectory40_frames_per_s": len(orbit) / total, "trajectory40_s": total, "first_frame_ms": 1000.0 * first,
+           "steady_frames_per_s_after_first": (len(orbit) - 1) / (total - first),
+           "adopted": {"cnn": (R2.cnn_calibration or {}).get("terms3x3"), "path": (R2.field_gate or {}).get("path"),
+                       "calibration_poses": ((R2.field_gate or {}).get("measurements") or {}).get("poses", 1)}}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    R2.set_style(synth.make_style(2222))
+    fused.prepare_style(R2)
+    fused.prepare_sky(R2)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    R2.calibrate_style(orbit[0], hw, args.samples, more_poses=orbit[20:21])
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    rec.update(style_setup_ms=1000.0 * (t1 - t0), calibration_ms=1000.0 * (t2 - t1))
+    del R2
+    return rec
+
+
 def rvip_roofline(R, poses, hw):
     """SURVEY 8(d) record of the ray marcher: algorithmic bytes = 4 B x DDA steps of the reference's cell-by-cell loop
     (ray_voxel_intersection.cu:115-229; counted by the measurement build of the same kernel, sdn_rvip_debug_counts, WITHOUT the
@@ -581,6 +670,8 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    from scenedreamer_amd import benchline
+    guard = benchline.StdoutGuard()      # from here on stdout belongs to the one JSON line; everything else lands on stderr
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or run "
@@ -645,10 +736,10 @@ def main():
     if args.only:       # just one of the extra records (one GPU)
         assert world == 1, "--only runs on one GPU"
         if args.only == "dropin":
-            print(json.dumps({"dropin": dropin_record(args, weights, scene, dev)}))
+            guard.emit(json.dumps({"dropin": dropin_record(args, weights, scene, dev)}))
         else:
             R.render_frame(poses[0], hw, args.samples, mode=mode)      # (the style's precision gates, as the headline run has them)
-            print(json.dumps({"other_configs": other_configs(args, R, weights, scene, poses, dev)}))
+            guard.emit(json.dumps({"other_configs": other_configs(args, R, weights, scene, poses, dev)}))
         return
 
     def barrier():
@@ -836,6 +927,24 @@ def main():
     if rank == 0 and world == 1 and mode == "fused" and not tile_parallel and not args.no_extras:
         early = early_termination_record(args, R, weights, scene, poses, hw, mode)
 
+    floor = style_cost = skip_off_fps = None
+    if rank == 0 and world == 1 and mode == "fused" and not tile_parallel and not args.no_extras:
+        try:
+            floor = floor_record(args, R, weights, scene, poses, hw, mode)
+        except Exception as ex:  # noqa: BLE001 -- an extra record must not cost the headline line
+            floor = {"error": f"{type(ex).__name__}: {ex}"}
+        try:        # the timed region's poses with colour-branch skipping off (bit-identical images; tests/test_fused_gpu.py)
+            R.colour_skip = False
+            skip_off_fps = 1000.0 / _trajectory_ms(R, timed_poses, hw, args.samples, mode, args.apron)
+        except Exception as ex:  # noqa: BLE001
+            sys.stderr.write(f"[bench] colour_skip_off: {type(ex).__name__}: {ex}\n")
+        finally:
+            R.colour_skip = None
+        try:
+            style_cost = style_cost_record(args, weights, scene, poses, hw, mode, dev)
+        except Exception as ex:  # noqa: BLE001
+            style_cost = {"error": f"{type(ex).__name__}: {ex}"}
+
     if rank == 0:
         fps = (1 if tile_parallel else world) * args.steps / elapsed
         out = {
@@ -873,6 +982,7 @@ def main():
             "roofline": roof, "roofline_grid_sampler": roof_grid, "roofline_cnn": roof_cnn, "roofline_rvip": roof_rvip,
             "roofline_sky": roof_sky,
             "early_termination": early,
+            "floor": floor, "colour_skip_off_frames_per_s": skip_off_fps, "style_cost": style_cost,
         }
         gates = {"cnn": getattr(R, "cnn_calibration", None),
                  "field": {k: v for k, v in (getattr(R, "field_gate", None) or {}).items() if k != "measurements"} or None,
@@ -943,7 +1053,15 @@ def main():
                     out["dropin"] = dropin_record(args, weights, scene, dev, getattr(cpu_baseline, "tiles", None))
                 except Exception as e:  # noqa: BLE001
                     out["dropin"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out))
+        # the full record -> bench_detail.json; its numeric extract (<= 6 KB, benchline.compact) -> the one stdout line
+        detail_path = os.environ.get("SDN_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(out, f, indent=1, default=str)
+        except OSError as e:
+            sys.stderr.write(f"[bench] could not write {detail_path}: {e}\n")
+            detail_path = None
+        guard.emit(benchline.line(out, detail_path))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

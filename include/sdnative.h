@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define SDN_ABI_VERSION 4
+/* 5: window_host grew from int32[5] to int32[6] (element 5: 8 x 4 pixel-block ray order) and sdn_field_aux gained
+ *    `colour_passes` + `flags` -- a caller built against version 4 would be read past its arrays / struct. */
+#define SDN_ABI_VERSION 5
 
 typedef void *sdn_stream_t; /* hipStream_t */
 

@@ -14,6 +14,7 @@ import torch  # noqa: F401  (must be imported before dlopen, see module docstrin
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsdnative.so")
+ABI_VERSION = 5      # include/sdnative.h SDN_ABI_VERSION
 
 SDN_F32, SDN_F16 = 0, 1
 
@@ -118,8 +119,9 @@ def lib():
                     fn = getattr(L, name)  # AttributeError if the symbol is not exported
                     fn.restype = res
                     fn.argtypes = args
-                if L.sdn_abi_version() != 4:
-                    raise ImportError("libsdnative ABI version mismatch")
+                if L.sdn_abi_version() != ABI_VERSION:
+                    raise ImportError(f"libsdnative ABI version {L.sdn_abi_version()} != {ABI_VERSION} expected by this package: "
+                                      "rebuild with `python -m scenedreamer_amd.build --force`")
                 _lib = L
     return _lib
 

@@ -291,5 +291,18 @@ def make_weights(seed=0, grid_log2_hashmap=19, with_embeddings=True):
     return w
 
 
+def fog_weights(weights, gain=0.03, level=6.0):
+    """A copy of `weights` whose density is a thin fog: sigma' = gain * sigma + level.  With the synthetic density head
+    (sigma ~ N(-4, 21)) that is 6 +- 0.65: strictly positive at every sample, and small enough that a ray's transmittance
+    after all its samples (free energy <= 10.5 * 3.0 * 0.25 * 24 / 26 = 7.3 -> T >= 7e-4) stays above the early-termination
+    threshold.  The regime in which NOTHING is removed: no ray terminates, no sample has weight zero, every colour of every
+    sample is composited (volum_rendering_relu, mc_utils.py:154-161) -- the floor of the frame rate and the worst case for
+    accumulated colour error."""
+    w = dict(weights)
+    w["render_net.fc_sigma.weight"] = (np.asarray(weights["render_net.fc_sigma.weight"], np.float32) * np.float32(gain)).astype(np.float32)
+    w["render_net.fc_sigma.bias"] = (np.asarray(weights["render_net.fc_sigma.bias"], np.float32) * np.float32(gain) + np.float32(level)).astype(np.float32)
+    return w
+
+
 def make_style(seed=8888):
     return normal(seed, "style_z", (1, STYLE_DIMS), 1.0)

@@ -118,7 +118,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/sdnative.h but not exported"
     assert set(capi.declared_symbols()) <= set(declared)
-    assert lib.sdn_abi_version() == 4
+    assert lib.sdn_abi_version() == capi.ABI_VERSION == 5
 
 
 def _header_prototypes():
@@ -556,3 +556,89 @@ def test_weight_ring_protocol_with_restarts():
                 restart(p + 1)
                 # exactly the state a kernel start has, shifted by g: the next three positions hold slots 0, 1, 2 of the next pass
                 assert [content[(g + sl) % NSLOT] for sl in range(AHEAD)] == [(p + 1, sl) for sl in range(AHEAD)] and next_in_pass == AHEAD
+
+
+# ---- bench.py's printed line (a 22.6 KB line the driver could not parse = an unmeasured round) -----------------
+def _canned_bench_record():
+    """The last full record a builder run produced in the old format (22.6 KB on one line): the worst case in size."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_bench_final.json")
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+def test_bench_line_is_small_numeric_and_complete():
+    import json
+    from scenedreamer_amd import benchline
+    full = _canned_bench_record()
+    assert len(json.dumps(full)) > 20000                 # the record the driver could not read
+    # the records this round adds, as bench.py fills them
+    full["floor"] = {"frames_per_s": 41.234567, "max_abs_err_vs_fp32": 4.4e-4, "weights": "x" * 300}
+    full["colour_skip_off_frames_per_s"] = 50.123456
+    full["style_cost"] = {"style_setup_ms": 3.21, "calibration_ms": 401.5, "first_frame_ms": 433.0, "trajectory40_frames_per_s": 36.6, "adopted": {"cnn": 1}}
+    s = benchline.line(full, "/somewhere/bench_detail.json")
+    assert "\n" not in s and len(s.encode()) < benchline.LINE_LIMIT <= 6144
+    rec = json.loads(s)
+    assert json.loads(benchline.dumps(rec)) == rec       # round trip
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "roofline_grid_sampler", "roofline_cnn", "roofline_rvip", "roofline_sky", "cpu_baseline", "precision"):
+        assert k in rec, k
+    assert rec["metric"] == full["metric"] and rec["steps"] == full["steps"] and rec["warmup"] == full["warmup"]
+    assert abs(rec["value"] - full["value"]) < 1e-3 * full["value"] and abs(rec["ms_per_step"] - full["ms_per_step"]) < 1e-3 * full["ms_per_step"]
+    assert set(rec["config"]) >= {"workload", "baseline_config", "path", "apron"} and "model" not in rec["config"]
+    roof = rec["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_finished_samples", "avg_launch_ms", "samples_evaluated", "traffic"):
+        assert k in roof, k
+    assert len(roof["kernel"]) <= 80 and roof["bound"] == "mfma" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4
+    assert set(rec["cpu_baseline"]) >= {"value", "unit", "cores", "kind"} and rec["cpu_baseline"]["kind"] in ("reference", "port")
+    assert set(rec["precision"]) >= {"max_abs_err", "bound"}
+    for k in ("dropin_frames_per_s", "config3_frames_per_s", "config5_1gpu_frames_per_s", "fallback_fp32_frames_per_s", "floor_frames_per_s",
+              "colour_skip_off_frames_per_s", "style_setup_ms", "calibration_ms", "first_frame_ms", "trajectory40_frames_per_s"):
+        assert isinstance(rec[k], float), k
+
+    # nothing but numbers, booleans, null and SHORT strings; no nested prose
+    def walk(v, depth=0):
+        if isinstance(v, dict):
+            assert depth < 2
+            for x in v.values():
+                walk(x, depth + 1)
+        elif isinstance(v, list):
+            assert all(isinstance(x, (int, float)) for x in v)
+        elif isinstance(v, str):
+            assert len(v) <= 120, v
+        else:
+            assert v is None or isinstance(v, (bool, int, float))
+    walk(rec)
+
+
+def test_bench_line_survives_missing_and_oversized_records():
+    import json
+    from scenedreamer_amd import benchline
+    # a multi-rank / --profile run: no cpu_baseline, no precision error, no extras; NaN must not reach the line
+    rec = json.loads(benchline.line({"metric": "m", "value": float("nan"), "unit": "frames/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+                                     "ms_per_step": 2.5, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                                     "data": "synthetic", "config": {"workload": "w" * 500}, "roofline": None,
+                                     "broadcast": {"broadcast_s": 0.031}, "other_configs": {"error": "x"}, "dropin": {"skipped": "y"}}))
+    assert rec["value"] is None and rec["roofline"] is None and rec["broadcast_s"] == 0.031 and len(rec["config"]["workload"]) <= 120
+    # a record that would not fit loses its optional parts, never its headline
+    big = _canned_bench_record()
+    big["stage_ms"] = {f"stage{i}": float(i) for i in range(600)}
+    s = benchline.line(big)
+    assert len(s) < benchline.LINE_LIMIT and "stage_ms" not in json.loads(s) and "roofline" in json.loads(s)
+
+
+def test_stdout_guard_leaves_exactly_one_line_on_stdout():
+    """Python prints, C-level writes and child processes between guard creation and emit all land on stderr."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, subprocess; sys.path.insert(0, %r)\n"
+            "from scenedreamer_amd import benchline\n"
+            "g = benchline.StdoutGuard()\n"
+            "print('Rendering frame 1')\n"
+            "os.write(1, b'library chatter\\n')\n"
+            "subprocess.run(['echo', 'child chatter'])\n"
+            "g.emit('{\"value\": 1}')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"value": 1}\n'
+    assert "Rendering frame 1" in r.stderr and "library chatter" in r.stderr and "child chatter" in r.stderr

@@ -8,6 +8,7 @@
 #   smoke      __graft_entry__.smoke()
 #   bench      bench.py headline (20 steps) without the CPU leg
 #   benchfull  bench.py exactly as the driver runs it (defaults)
+#   driver     bench.py as the driver runs it (--gpus 1 --steps 20 --warmup 5) + the parse check on the stdout tail
 #   dropin     bench.py --only dropin
 #   light      tools/prof_light.sh: test subset + kernel trace + PMC passes + the driver's bench command (evidence refresh)
 #   prof       tools/prof_final.sh: full suite + driver bench + rocprofv3 kernel trace + PMC passes, summaries -> gpurun_out/<label>_*
@@ -27,6 +28,12 @@ for step in "$@"; do
     smoke) timeout 600 python __graft_entry__.py smoke > gpurun_out/${label}_smoke.log 2>&1; echo "rc=$?"; grep "\[smoke\]" gpurun_out/${label}_smoke.log ;;
     bench) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${label}_bench.json 2> gpurun_out/${label}_bench.err; echo "rc=$?"; tail -c 1500 gpurun_out/${label}_bench.json; tail -5 gpurun_out/${label}_bench.err ;;
     benchfull) timeout 900 python bench.py > gpurun_out/${label}_benchfull.json 2> gpurun_out/${label}_benchfull.err; echo "rc=$?"; tail -c 3000 gpurun_out/${label}_benchfull.json; tail -5 gpurun_out/${label}_benchfull.err ;;
+    driver) # the driver's exact command; the check it applies: the LAST stdout line (inside an 8 KB tail) must parse as JSON
+            ( time timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${label}_driver.out 2> gpurun_out/${label}_driver.err ); echo "rc=$?"
+            cp bench_detail.json gpurun_out/${label}_bench_detail.json 2>/dev/null
+            wc -l -c gpurun_out/${label}_driver.out
+            tail -c 8192 gpurun_out/${label}_driver.out | tail -1 | python3 -m json.tool > gpurun_out/${label}_driver_parsed.json && echo "PARSED OK" || echo "PARSE FAILED"
+            cat gpurun_out/${label}_driver.out; tail -5 gpurun_out/${label}_driver.err ;;
     dropin) timeout 900 python bench.py --only dropin > gpurun_out/${label}_dropin.json 2> gpurun_out/${label}_dropin.err; echo "rc=$?"; tail -c 3000 gpurun_out/${label}_dropin.json; tail -8 gpurun_out/${label}_dropin.err ;;
     light) bash tools/prof_light.sh "$(cat tools/.commit 2>/dev/null)" $label ;;
     prof)  bash tools/prof_final.sh "$(cat tools/.commit 2>/dev/null)" $label ;;
