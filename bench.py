@@ -549,7 +549,7 @@ def style_cost_record(args, weights, scene, poses, hw, mode, dev):
     torch.cuda.synchronize()
     orbit = [poses[k % len(poses)] for k in range(40)]
     t0 = time.perf_counter()
-    R2.set_style(synth.make_style(1111))
+    R2.set_style(synth.make_style(8888))     # (the benchmark's style: the field's work is content dependent; everything per-style is redone)
     first = None
     for k, im in enumerate(R2.render_frames(orbit, hw, args.samples, mode=mode, apron=args.apron)):
         if k == 0:
@@ -563,7 +563,7 @@ def style_cost_record(args, weights, scene, poses, hw, mode, dev):
                        "calibration_poses": ((R2.field_gate or {}).get("measurements") or {}).get("poses", 1)}}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    R2.set_style(synth.make_style(2222))
+    R2.set_style(synth.make_style(8888))
     fused.prepare_style(R2)
     fused.prepare_sky(R2)
     torch.cuda.synchronize()
@@ -749,11 +749,13 @@ def main():
 
     if world > 1 and mode == "fused":
         # one decision of the render CNN's precision gate for the whole job (every rank renders the same frame; MAX over ranks)
-        sdist.agree_cnn_precision(R, poses[0], (540, 960) if tile_parallel else hw, args.samples)
+        # (the trajectory loop's policy: the first pose of the timed trajectory + its middle pose, MAX-combined, then over the ranks)
+        sdist.agree_precision(R, frame_pose(0), hw, args.samples,
+                              more_poses=() if tile_parallel else (frame_pose(max(1, (args.warmup + args.steps) // 2)),))
 
     def render_one(pz):
-        if tile_parallel:
-            return sdist.render_frame_tile_parallel(R, pz, hw, args.samples, mode=mode)
+        if tile_parallel:     # bands cut by the static row-cost model x the measured feedback of the frames before (dist.rebalance_scale)
+            return sdist.render_frame_tile_parallel(R, pz, hw, args.samples, mode=mode, balance="feedback", stats={})
         return R.render_frame(pz, hw, args.samples, mode=mode, apron=args.apron)
 
     pipelined = not (args.no_overlap or mode != "fused" or tile_parallel)
@@ -792,7 +794,7 @@ def main():
     tp_stats = None
     if tile_parallel:       # one more frame, outside the timed region, with per-rank device timing of the bands
         tp_stats = {}
-        sdist.render_frame_tile_parallel(R, frame_pose(args.warmup), hw, args.samples, mode=mode, stats=tp_stats)
+        sdist.render_frame_tile_parallel(R, frame_pose(args.warmup), hw, args.samples, mode=mode, balance="feedback", stats=tp_stats)
         barrier()
     frame_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     pct = lambda q: frame_ms[min(len(frame_ms) - 1, int(round(q * (len(frame_ms) - 1))))]
@@ -952,7 +954,9 @@ def main():
             "metric": f"rendered frames/sec @{args.width}\u00d7{args.height}, {args.samples} samples/ray, scene_size {args.scene_size}; HBM GB/s",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if tile_parallel else "weak",
+            # config 5: one frame split over the ranks; config 4: the 256 frames of the orbit split over the ranks (K = 256 / N per rank):
+            # both fixed total work = strong.  Default (and what the driver's SCALE run is): every rank renders K frames = weak.
+            "scaling": "strong" if (tile_parallel or args.config == 4) else "weak",
             "vs_baseline": None, "dtype": R.compute_dtype(mode), "data": "synthetic",
             "config": {"workload": f"{args.width}x{args.height}, num_samples={args.samples}, "
                                    f"scene_size={args.scene_size}, cam pattern 0 (pose stride {args.pose_stride} of {maxstep} poses), "

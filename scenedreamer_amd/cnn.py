@@ -32,7 +32,11 @@ def form_key(terms3x3):
     if isinstance(terms3x3, (tuple, list)):
         terms3x3 = "".join(str(int(t)) for t in terms3x3)
     if isinstance(terms3x3, str):
-        assert len(terms3x3) == 4 and set(terms3x3) <= {"1", "3"}, terms3x3
+        terms3x3 = terms3x3.strip()
+        if terms3x3 in ("1", "3"):          # (environment variables arrive as strings)
+            return int(terms3x3)
+        if not (len(terms3x3) == 4 and set(terms3x3) <= {"1", "3"}):
+            raise ValueError(f"3x3 precision form {terms3x3!r}: expected 1, 3 or four characters of 1 / 3 (conv2a, conv2b, conv3a, conv3b), e.g. 1113")
         return 1 if terms3x3 == "1111" else 3 if terms3x3 == "3333" else terms3x3
     assert int(terms3x3) in (1, 3), terms3x3
     return int(terms3x3)

@@ -237,12 +237,41 @@ def balanced_row_bands(costs, world, min_rows=MIN_BAND_ROWS):
     return [(cuts[k], cuts[k + 1]) for k in range(world)]
 
 
+FEEDBACK_DAMPING = 0.7      # rebalance_scale: exponent on the measured / predicted ratio (1 = trust one frame completely)
+FEEDBACK_CLAMP = (0.5, 2.0)  # ... and the range one update may move a band's rows by
+
+
+def rebalance_scale(costs, scale, bands, band_ms, damping=FEEDBACK_DAMPING):
+    """Measured feedback for the band cut: `costs * scale` predicted each band's share of the frame, `band_ms` is what the bands
+    took.  Returns the new per-row multipliers: the rows of band k are multiplied by (measured share / predicted share) ** damping,
+    clamped, and the result renormalised to mean 1.  A pure function of its arguments: every rank holds the same costs, scale,
+    bands and (all-reduced) band_ms, so all ranks reach the same next cut without exchanging anything more.
+    The static model (Renderer.row_costs: hits + MISS_COST x width) cannot know what the field does with a ray -- colour-branch
+    skipping and early termination make the cost of a hit content-dependent -- and at 8 bands of a 4K frame it was off by 16 %
+    (profiles/r05_dist_config5_8ranks_1gpu.json); consecutive frames of a trajectory look alike, so one measured frame corrects
+    the next (tools/band_balance.py: imbalance per iteration on the real frame)."""
+    costs = np.asarray(costs, np.float64)
+    scale = np.ones_like(costs) if scale is None else np.asarray(scale, np.float64).copy()
+    ms = np.asarray(band_ms, np.float64)
+    pred = np.asarray([float((costs[a:b] * scale[a:b]).sum()) for a, b in bands])
+    if not (np.isfinite(ms).all() and ms.sum() > 0 and pred.sum() > 0 and len(ms) == len(bands)):
+        return scale
+    ratio = (ms / ms.sum()) / np.maximum(pred / pred.sum(), 1e-12)
+    ratio = np.clip(ratio ** damping, *FEEDBACK_CLAMP)
+    for (a, b), r in zip(bands, ratio):
+        scale[a:b] *= r
+    return scale / scale.mean()
+
+
 def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode="fused", group=None, balance=True, stats=None):
     """Every rank renders one row band of the frame; the only exchange step of the path is the frame-wide sky mean:
     all_reduce(sum) of 64+1 numbers.  Rank 0 receives the stitched image [1,3,H,W]; the other ranks return None.
 
     balance: bands of equal estimated work (balanced_row_bands on renderer.row_costs(pose, hw): a 1/16-resolution ray cast every
-    rank performs for itself -- bit-identical everywhere, so no exchange) instead of equal height.
+    rank performs for itself -- bit-identical everywhere, so no exchange) instead of equal height.  balance="feedback": the
+    estimate is additionally multiplied by the per-row factors the previous timed frames of this resolution produced
+    (rebalance_scale on the all-reduced band times: the same update on every rank); needs `stats` -- the per-band device
+    times are what it learns from, one host synchronisation per frame, which the gather to rank 0 implies anyway.
     stats: optional dict; receives "bands", and -- measured with device events around this rank's work, exchanged in one extra
     all_reduce of `world` numbers -- "band_ms" (per rank) and "imbalance" = max / mean.
 
@@ -256,9 +285,17 @@ def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode=
             getattr(renderer, "cnn_terms3x3", None) is None):
         # bands of one frame must not mix precisions: the per-style gates are decided for the job before the first band (every
         # rank reaches this point for the same frame with the same, still undecided, state -- the style was set on all of them)
-        agree_precision(renderer, pose, (min(H, 540), min(W, 960)), num_samples, group)
+        # (the frame's own resolution -- calibrate_one reduces frames above CAL_MAX_PIXELS by itself and measures on a window)
+        agree_precision(renderer, pose, (H, W), num_samples, group)
+    costs = fb = None
     if balance and world > 1 and hasattr(renderer, "row_costs"):
-        bands = balanced_row_bands(renderer.row_costs(pose, resolution_hw), world)
+        costs = np.asarray(renderer.row_costs(pose, resolution_hw), np.float64)
+        if balance == "feedback":
+            fb = renderer.__dict__.setdefault("_band_feedback", {})
+            sc = fb.get((H, W, world))
+            bands = balanced_row_bands(costs * sc if sc is not None else costs, world)
+        else:
+            bands = balanced_row_bands(costs, world)
     else:
         bands = row_bands(H, world)
     row0, row1 = bands[rank]
@@ -291,6 +328,8 @@ def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode=
             ms = [float(x) for x in v.tolist()]
             stats["band_ms"] = ms
             stats["imbalance"] = max(ms) / (sum(ms) / len(ms)) if sum(ms) > 0 else None
+            if fb is not None:
+                fb[(H, W, world)] = rebalance_scale(costs, fb.get((H, W, world)), bands, ms)
     if world == 1:
         return img
     hmax = max(b[1] - b[0] for b in bands)
@@ -302,18 +341,20 @@ def render_frame_tile_parallel(renderer, pose, resolution_hw, num_samples, mode=
     return torch.cat([o[:, :, :b[1] - b[0]] for o, b in zip(outs, bands)], dim=2)
 
 
-def agree_precision(renderer, pose, resolution_hw, num_samples, group=None):
+def agree_precision(renderer, pose, resolution_hw, num_samples, group=None, more_poses=()):
     """The renderer's per-style precision gates (Renderer.calibrate_style: colour layers fp6 / 3-term, 3x3 convolutions 1-term /
     3-term, fused path / fp32 fallback -- measured end to end against the fp32 frame) evaluated ONCE FOR THE JOB: every rank
     calibrates on the same frame (`pose`; renders are bit-reproducible, so every rank measures the same errors), the
     measurements are reduced with MAX, and every rank adopts the decisions that follow from the reduced values
     (Renderer.adopt_precision) -- bands of one frame, or frames of one trajectory, never mix precisions.  Explicit settings
-    stay as they are.  Returns {"cnn": cnn_calibration, "field": field_gate}."""
+    stay as they are.  more_poses: further poses measured and MAX-combined, as the single-process trajectory loop does with
+    the middle pose of its trajectory (Renderer.calibrate_style) -- the same policy, so a multi-rank job cannot adopt a cheaper
+    rung than one process would for the same style and trajectory.  Returns {"cnn": cnn_calibration, "field": field_gate}."""
     renderer.cnn_calibration = None
     renderer.field_gate = None
     renderer.colour_terms_auto = None
     renderer.sky_terms_auto = None
-    meas = renderer.calibrate_style(pose, resolution_hw, num_samples)["measurements"]
+    meas = renderer.calibrate_style(pose, resolution_hw, num_samples, more_poses=more_poses)["measurements"]
     if _is_init() and dist.get_world_size(group) > 1:
         world = dist.get_world_size(group)
         slots = [(a, k) for a in ("field_err", "image_err", "sky_err", "cnn_diffs") for k in sorted(meas.get(a) or {}, key=str)]

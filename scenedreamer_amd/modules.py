@@ -54,6 +54,7 @@ class Backend:
         self._bound = {}
         self._zkey = {}
         self._zref = {}     # the style tensor each _zkey was taken from, kept ALIVE: see style()
+        self.sky_terms_auto = self._sky_gate_key = self.sky_gate = None
 
     @staticmethod
     def tensors_key(module):
@@ -86,7 +87,16 @@ class Backend:
             self.cnn_calibration = None
         if prefix == "hash_encoder.":
             self._fused_scene = None
+        if prefix == "sky_net.":
+            self._reset_sky_gate()
         return True
+
+    def _reset_sky_gate(self):
+        """The sky MLP's hidden-layer form is a per-style, per-weights MEASUREMENT (SKYMLPNative.forward): new weights or a new
+        style start from the 3-term form until it has been re-measured."""
+        self.sky_terms_auto = None
+        self._sky_gate_key = None
+        self.sky_gate = None
 
     def style(self, prefix, z, item, fold):
         """Fold style code z[item] for the network under `prefix` unless that very tensor content was folded already.
@@ -101,6 +111,8 @@ class Backend:
             fold(self, z[item:item + 1].detach().to(torch.float32).reshape(1, -1))
             self._zkey[prefix] = key
             self._zref[prefix] = z
+            if prefix == "sky_net.":
+                self._reset_sky_gate()
 
 
 def _backend(module):

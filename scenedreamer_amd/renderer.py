@@ -297,12 +297,11 @@ class Renderer:
             meas["poses"] = meas.get("poses", 1) + 1
         return self.adopt_precision(meas)
 
-    def calibrate_one(self, pose, resolution_hw, num_samples):
+    def calibrate_one(self, pose, resolution_hw, num_samples, crop_px=None):
         """Measure END TO END, for the CURRENT weights and style, what the reduced-precision choices of the fused path cost, and
-        decide.  One frame (`pose`; at most CAL_MAX_PIXELS pixels -- a larger frame is calibrated at a reduced resolution) is
-        rendered by the reference's op sequence in fp32 (field_unfused + render_cnn: PyTorch fp32 + the drop-in HIP ops -- the
-        path the CPU-oracle tests validate; samples placed by the fused kernel's own device function, see field_unfused) and by
-        the candidates; the cheapest candidate inside the bounds is adopted:
+        decide.  A window of one frame (`pose`) is rendered by the reference's op sequence in fp32 (field_unfused + render_cnn:
+        PyTorch fp32 + the drop-in HIP ops -- the path the CPU-oracle tests validate; samples placed by the fused kernel's own
+        device function, see field_unfused) and by the candidates; the cheapest candidate inside the bounds is adopted:
 
           colour layers fc_5 / fc_6: f16 + MX-fp6 corrections (colour_terms 6) if net_out stays within COLOUR_AUTO_BOUND of the
             3-term evaluation, else the 3-term split;
@@ -313,16 +312,27 @@ class Renderer:
             MEASURED total error against the fp32 image (field error included) stays within IMAGE_AUTO_BOUND; if not even the
             3-term image is within IMAGE_AUTO_BOUND, the fp32 path.
 
+        The window (round 6; `crop_px`, default CAL_CROP = 256 output pixels square, 0 = the whole frame as in rounds 4-5): the fp32
+        twin of a whole 960x540x24 frame is 0.25 s of GPU time per pose -- with two poses more than half of a 40-frame trajectory
+        (0.72 s).  The field is evaluated per ray and the CNN's receptive radius is 4 px, so any window of the frame is a valid
+        sample of both; the window is put where the frame's content changes most from pixel to pixel (box sum of first-hit block-id
+        changes and depth steps, straight from the ray caster's output: silhouettes and material boundaries, where net_out -- and
+        with it the f16 rounding of the one-product 3x3 layers -- varies most).  A maximum over 1/8 of the pixels under-estimates
+        the frame's (extreme-value growth ~ sqrt(2 ln N): 1.08 here), so every window-measured maximum is charged times
+        CAL_CROP_FACTOR = 1.15 before it meets a bound (`raw` keeps the measured values).  The fused sky MLP runs on every ray of
+        the padded frame (its frame mean needs them), its fp32 twin on the window's rays.
+
         The errors depend on the loaded weights (the density head amplifies hidden-activation error; 3x3 gains compound over
         four layers): tests/test_precision_gates_gpu.py scales them until every gate closes.  Explicit settings (set_precision,
-        SDN_MLP_COLOUR_TERMS, SDN_CNN_TERMS) are measured but not overridden.  Costs one fp32 frame (~0.2 s at 960x540x24) per
-        pose.  Returns the measurements; calibrate_style turns them into the records `field_gate`, `cnn_calibration` (bench.py
-        prints both)."""
+        SDN_MLP_COLOUR_TERMS, SDN_CNN_TERMS) are measured but not overridden.  Returns the measurements; calibrate_style turns
+        them into the records `field_gate`, `cnn_calibration` (bench.py writes both to bench_detail.json)."""
         from . import fused
         H, W = resolution_hw
         if H * W > CAL_MAX_PIXELS:
             f = (CAL_MAX_PIXELS / float(H * W)) ** 0.5
             H, W = max(8, int(H * f)), max(8, int(W * f))
+        if crop_px is None:
+            crop_px = int(os.environ.get("SDN_CAL_CROP", CAL_CROP))
         crop = self.pad // 2
         with torch.no_grad():
             vid, d2, rd, (H0, W0) = self.cast_rays(pose, (H, W))
@@ -330,60 +340,99 @@ class Renderer:
             vid, d2, rd = vid.view(n, self.M), d2.view(2, n, self.M), rd.view(n, 3)
             ori = torch.as_tensor(pose[0], dtype=torch.float32).reshape(3)
             inner = (lambda im: im[:, :, crop:-crop, crop:-crop]) if crop else (lambda im: im)
-            # ---- the fp32 frame
-            sky32 = self.sky_features(rd)
-            savg32 = sky32.mean(dim=0, keepdim=True)
-            ori_dev = ori.to(self.dev)
-            ref_no = torch.cat([self.field_unfused(vid[r:r + CAL_CHUNK], d2[:, r:r + CAL_CHUNK].contiguous(), rd[r:r + CAL_CHUNK], ori_dev,
-                                                   sky32[r:r + CAL_CHUNK], savg32, num_samples, placement="kernel")
-                                for r in range(0, n, CAL_CHUNK)], dim=0)
-            ref_img = inner(self.render_cnn(ref_no.view(1, H0, W0, 64)))
-            # ---- the sky MLP: hidden layers as f16 + fp6 corrections if its features stay within SKY_AUTO_BOUND of the fp32 ones
-            explicit_sky = getattr(self, "sky_terms", None) or (int(os.environ["SDN_SKY_TERMS"]) if "SDN_SKY_TERMS" in os.environ else None)
-            self.sky_terms_auto = None
-            sky_c, sky_avg = fused.sky_fused(self, rd)
-            sky_err = {fused.sky_terms(self): float((sky_c - sky32).abs().max())}
-            if explicit_sky is None:
-                self.sky_terms_auto = 6
-                c6, a6 = fused.sky_fused(self, rd)
-                sky_err[6] = float((c6 - sky32).abs().max())
-                if sky_err[6] <= SKY_AUTO_BOUND:
-                    sky_c, sky_avg = c6, a6
-                else:
-                    self.sky_terms_auto = None
-            # ---- the fused field
+            # ---- the window: where the frame's content changes most from pixel to pixel -- silhouettes, material boundaries, depth
+            #      steps of the first hit (from the ray caster's output: no field evaluation needed) -- is where net_out varies most
             explicit_ct = getattr(self, "colour_terms", None)
             if explicit_ct is None and "SDN_MLP_COLOUR_TERMS" in os.environ:
                 explicit_ct = int(os.environ["SDN_MLP_COLOUR_TERMS"])
             saved = getattr(self, "colour_terms", None)
+            Hc, Wc, r0, c0 = H0, W0, 0, 0
+            windowed = bool(crop_px) and (H0 > crop_px + self.pad + 32 or W0 > crop_px + self.pad + 32)
+            if windowed:
+                Hc, Wc = min(H0, crop_px + self.pad), min(W0, crop_px + self.pad)
+                v0 = vid[:, 0].view(H0, W0)
+                t0 = torch.nan_to_num(d2[0][:, 0], nan=-64.0).view(H0, W0)
+                g = torch.zeros(H0, W0, device=self.dev)
+                g[1:] += (v0[1:] != v0[:-1]).float() + ((t0[1:] - t0[:-1]).abs() > 1.0).float()
+                g[:, 1:] += (v0[:, 1:] != v0[:, :-1]).float() + ((t0[:, 1:] - t0[:, :-1]).abs() > 1.0).float()
+                g += 1e-3 * (v0 != 0).float()           # (ties: prefer ground to sky)
+                box = F.avg_pool2d(g[None, None], (Hc, Wc), stride=8)[0, 0]
+                k = int(box.argmax())
+                r0, c0 = (k // box.shape[1]) * 8, (k % box.shape[1]) * 8
+                del g, box
+            nc = Hc * Wc
+            cut = lambda t, last: t.view(H0, W0, last)[r0:r0 + Hc, c0:c0 + Wc].reshape(nc, last).contiguous()
+            if windowed:
+                vid_c, rd_c = cut(vid, self.M), cut(rd, 3)
+                d2_c = torch.stack([cut(d2[0], self.M), cut(d2[1], self.M)]).contiguous()
+            else:
+                vid_c, rd_c, d2_c = vid, rd, d2
+            # ---- the sky MLP: hidden layers as f16 + fp6 corrections if its features stay within SKY_AUTO_BOUND of the fp32 ones.
+            #      The fused forms run on every ray of the padded frame (the frame mean needs them; 0.8 ms each); the fp32 twin on the
+            #      window's rays, its frame mean taken from the 3-term evaluation (4e-6 per feature before averaging 564 k of them)
+            ori_dev = ori.to(self.dev)
+            explicit_sky = getattr(self, "sky_terms", None) or (int(os.environ["SDN_SKY_TERMS"]) if "SDN_SKY_TERMS" in os.environ else None)
+            sky32_c = self.sky_features(rd_c)
+            self.sky_terms_auto = None
+            sky_c, sky_avg = fused.sky_fused(self, rd)
+            savg32 = sky_avg.reshape(1, 64) if (windowed and fused.sky_terms(self) == 3) else None
+            cut_sky = (lambda t: cut(t, 64)) if windowed else (lambda t: t)
+            sky_err = {fused.sky_terms(self): float((cut_sky(sky_c) - sky32_c).abs().max()) * (CAL_CROP_FACTOR if windowed else 1.0)}
+            if explicit_sky is None:
+                self.sky_terms_auto = 6
+                c6, a6 = fused.sky_fused(self, rd)
+                sky_err[6] = float((cut_sky(c6) - sky32_c).abs().max()) * (CAL_CROP_FACTOR if windowed else 1.0)
+                if sky_err[6] <= SKY_AUTO_BOUND:
+                    sky_c, sky_avg = c6, a6
+                else:
+                    self.sky_terms_auto = None
+            if savg32 is None:      # whole frame (or an explicit fp6 sky): the fp32 mean over every ray
+                savg32 = (sky32_c if not windowed else self.sky_features(rd)).mean(dim=0, keepdim=True)
+            skyc_c = cut_sky(sky_c)
+            # ---- the fp32 twin of the window
+            ref_no = torch.cat([self.field_unfused(vid_c[r:r + CAL_CHUNK], d2_c[:, r:r + CAL_CHUNK].contiguous(), rd_c[r:r + CAL_CHUNK], ori_dev,
+                                                   sky32_c[r:r + CAL_CHUNK], savg32, num_samples, placement="kernel")
+                                for r in range(0, nc, CAL_CHUNK)], dim=0)
+            ref_img = inner(self.render_cnn(ref_no.view(1, Hc, Wc, 64)))
+            # ---- the fused field on the window's rays
             no = {}
             try:
                 for ct in ((explicit_ct,) if explicit_ct is not None else (6, 3)):
                     self.colour_terms = ct
-                    no[ct] = fused.field_fused(self, vid, d2, rd, ori, sky_c, sky_avg, num_samples)
+                    no[ct] = fused.field_fused(self, vid_c, d2_c, rd_c, ori, skyc_c, sky_avg, num_samples)
             finally:
                 self.colour_terms = saved
-            meas = {"field_err": {ct: float((v - ref_no).abs().max()) for ct, v in no.items()}, "sky_err": sky_err, "explicit_sky": explicit_sky}
+            k_ev = CAL_CROP_FACTOR if windowed else 1.0       # window maxima are charged with the extreme-value factor
+            raw = {"field_err": {ct: float((v - ref_no).abs().max()) for ct, v in no.items()}}
+            meas = {"field_err": {ct: e * k_ev for ct, e in raw["field_err"].items()}, "sky_err": sky_err, "explicit_sky": explicit_sky}
             if explicit_ct is None:
-                meas["colour_diff"] = float((no[6] - no[3]).abs().max())
+                raw["colour_diff"] = float((no[6] - no[3]).abs().max())
+                meas["colour_diff"] = raw["colour_diff"] * k_ev
             ct = explicit_ct if explicit_ct is not None else (6 if meas["colour_diff"] <= COLOUR_AUTO_BOUND else 3)
             # ---- the render CNN on the chosen field's output
+            from .cnn import CNN_LADDER, form_key
             explicit_t = getattr(self, "cnn_terms3x3", None)
             if explicit_t is None and "SDN_CNN_TERMS" in os.environ:
-                explicit_t = int(os.environ["SDN_CNN_TERMS"])
-            x = no[ct].view(1, H0, W0, 64)
-            from .cnn import CNN_LADDER, form_key
+                explicit_t = form_key(os.environ["SDN_CNN_TERMS"])       # "1", "3" or a per-layer form like "1113"
+            x = no[ct].view(1, Hc, Wc, 64)
             if explicit_t is not None:
                 explicit_t = form_key(explicit_t)
             # (every rung is measured, whichever is adopted: adopt_precision must be a function of `meas` alone, so that the ranks of
             #  a multi-GPU job can reduce the measurements and reach the same decision)
             imgs = {t: inner(self._cnn_form(t)(x)).clone() for t in ((explicit_t,) if explicit_t is not None else CNN_LADDER)}
-            meas["image_err"] = {t: float((im - ref_img).abs().max()) for t, im in imgs.items()}
+            raw["image_err"] = {t: float((im - ref_img).abs().max()) for t, im in imgs.items()}
+            meas["image_err"] = {t: e * k_ev for t, e in raw["image_err"].items()}
             if explicit_t is None:
-                meas["cnn_diffs"] = {t: float((imgs[t] - imgs[3]).abs().max()) for t in CNN_LADDER if t != 3}
+                raw["cnn_diffs"] = {t: float((imgs[t] - imgs[3]).abs().max()) for t in CNN_LADDER if t != 3}
+                meas["cnn_diffs"] = {t: e * k_ev for t, e in raw["cnn_diffs"].items()}
                 meas["cnn_diff"] = meas["cnn_diffs"][1]
-        meas.update(explicit_colour=explicit_ct, explicit_cnn=explicit_t, pixels=int(H * W), rays=int(n), samples_per_ray=int(num_samples),
-                    frame=f"{W}x{H} (+{self.pad}-px apron), {num_samples} samples/ray")
+            if windowed:        # (a window's activation planes are not the frame's: drop them, the packed weights stay)
+                for c in self.__dict__.get("_mfma_cnns", {}).values():
+                    c._planes.pop((Hc, Wc), None)
+        meas.update(explicit_colour=explicit_ct, explicit_cnn=explicit_t, pixels=int((Hc - 2 * crop) * (Wc - 2 * crop)), rays=int(nc), samples_per_ray=int(num_samples),
+                    frame=f"{W}x{H} (+{self.pad}-px apron), {num_samples} samples/ray" +
+                          (f"; window {Wc - 2 * crop}x{Hc - 2 * crop} at ({r0},{c0}), maxima x {CAL_CROP_FACTOR}" if windowed else ""),
+                    window=([r0, c0, Hc, Wc] if windowed else None), raw=raw if windowed else None)
         return meas
 
     def adopt_precision(self, meas):
@@ -410,7 +459,7 @@ class Renderer:
                    "max_abs_diff_vs_3term": {str(k): v for k, v in diffs.items()},
                    "image_err_vs_fp32": {("1-term" if k == 1 else "3-term" if k == 3 else str(k)): v for k, v in ierr.items()},
                    "image_bound": IMAGE_AUTO_BOUND, "ladder": [str(k) for k in CNN_LADDER],
-                   "pixels": max(meas["pixels"], CNN_CAL_PIXELS), "calls": 1, "frame": meas["frame"], "measured": "end to end (calibrate_style)"}
+                   "pixels": CNN_CAL_PIXELS, "pixels_measured": meas["pixels"], "calls": 1, "frame": meas["frame"], "measured": "end to end (calibrate_style)"}
         self.field_gate = {
             "path": path, "max_abs_err_vs_fp32": ferr, "bound": FIELD_AUTO_BOUND, "quantity": "net_out (per-ray feature, range [-1, 1])",
             "colour": ({"terms": ct, "set_explicitly": True} if ect is not None else
@@ -426,6 +475,52 @@ class Renderer:
             self.cnn_calibration = cal
             self._drop_other_cnn_planes(cal["terms3x3"])
         return self.field_gate
+
+    def recheck_cnn(self, net_out):
+        """Once per style, on a LATER frame than the ones calibrate_style saw (the trajectory loop passes its last frame's
+        net_out [1,Hp,Wp,64]): the adopted 3x3 rung against the 3-term form on the window where this frame's net_out varies
+        most, maximum charged like calibrate_one's.  Two calibration poses decide for a whole trajectory and the margins are thin
+        by construction (a style may adopt a rung at 4.97e-4 against 5e-4): if the later pose disagrees, warn and step up the
+        ladder for the rest of the style.  ~1.5 ms + one host read, once per style."""
+        cal = getattr(self, "cnn_calibration", None)
+        if (not cal or cal.get("recheck") is not None or cal["terms3x3"] == 3 or getattr(self, "cnn_terms3x3", None) is not None
+                or "SDN_CNN_TERMS" in os.environ or os.environ.get("SDN_CNN_RECHECK", "1") == "0"):
+            return None
+        from .cnn import CNN_LADDER, form_key
+        bound = float(cal.get("bound") or CNN_AUTO_BOUND)
+        _, Hp, Wp, _ = net_out.shape
+        side = CAL_CROP + 2 * CNN_HALO
+        Hc, Wc = min(Hp, side), min(Wp, side)
+        with torch.no_grad():
+            v = net_out[0]
+            g = torch.zeros(Hp, Wp, device=net_out.device)
+            g[1:] += (v[1:] - v[:-1]).abs().sum(dim=-1)
+            g[:, 1:] += (v[:, 1:] - v[:, :-1]).abs().sum(dim=-1)
+            box = F.avg_pool2d(g[None, None], (Hc, Wc), stride=8)[0, 0]
+            k = int(box.argmax())
+            r0, c0 = (k // box.shape[1]) * 8, (k % box.shape[1]) * 8
+            x = net_out[:, r0:r0 + Hc, c0:c0 + Wc].contiguous()
+            ref3 = self._cnn_form(3)(x).clone()
+            ladder = list(CNN_LADDER)
+            start = ladder.index(form_key(cal["terms3x3"]))
+            seen = {}
+            adopted = 3
+            for cand in ladder[start:]:
+                if cand == 3:
+                    break
+                seen[str(cand)] = float((self._cnn_form(cand)(x) - ref3).abs().max()) * CAL_CROP_FACTOR
+                if seen[str(cand)] <= bound:
+                    adopted = cand
+                    break
+            for c in self.__dict__.get("_mfma_cnns", {}).values():      # the window's planes are not the frame's
+                c._planes.pop((Hc, Wc), None)
+        cal["recheck"] = {"window": [r0, c0, Hc, Wc], "max_abs_diff_vs_3term_charged": seen, "bound": bound, "adopted_before": cal["terms3x3"],
+                          "adopted_after": adopted}
+        if adopted != cal["terms3x3"]:
+            warnings.warn(f"render CNN: rung {cal['terms3x3']} adopted on the calibration poses measures {seen} > {bound:g} on a later frame of the "
+                          f"style; stepping up to {adopted}")
+            cal["terms3x3"] = adopted
+        return cal["recheck"]
 
     def _drop_other_cnn_planes(self, keep):
         """The forms not chosen keep their packed weights (9 MB each), not their activation planes (1.2 GB at 960x540)."""
@@ -465,7 +560,7 @@ class Renderer:
 
         want = getattr(self, "cnn_terms3x3", None)
         if want is None and "SDN_CNN_TERMS" in os.environ:
-            want = int(os.environ["SDN_CNN_TERMS"])
+            want = os.environ["SDN_CNN_TERMS"]          # form_key (in _cnn_form) reads "1", "3" and per-layer forms like "1113"
         if want is not None:
             return get(want)
         cal = getattr(self, "cnn_calibration", None)
@@ -486,10 +581,10 @@ class Renderer:
                 for cand in CNN_LADDER:
                     if cand != 3 and fits(worst.get(str(cand), 0.0)):
                         worst[str(cand)] = max(worst.get(str(cand), 0.0), float((ref3 - get(cand)(net_out)).abs().max()))
-            t = next((cand for cand in CNN_LADDER if cand != 3 and fits(worst[str(cand)])), 3)
+            t = next((cand for cand in CNN_LADDER if cand != 3 and fits(worst.get(str(cand), float("inf")))), 3)
             px = int(net_out.shape[1] * net_out.shape[2])
             cal = self.cnn_calibration = {
-                "terms3x3": t, "max_abs_diff_1term_vs_3term": worst["1"], "max_abs_diff_vs_3term": worst, "bound": bound,
+                "terms3x3": t, "max_abs_diff_1term_vs_3term": worst.get("1"), "max_abs_diff_vs_3term": worst, "bound": bound,
                 "ladder": [str(k) for k in CNN_LADDER],
                 "field_err_charged": field_err, "image_budget": IMAGE_BUDGET, "pixels": (cal["pixels"] if cal else 0) + px,
                 "calls": (cal["calls"] if cal else 0) + 1,
@@ -505,7 +600,7 @@ class Renderer:
         from . import fused
         ct, _ = fused.precision_profile(self)
         cal = getattr(self, "cnn_calibration", None)
-        t3 = getattr(self, "cnn_terms3x3", None) or (int(os.environ["SDN_CNN_TERMS"]) if "SDN_CNN_TERMS" in os.environ else None)
+        t3 = getattr(self, "cnn_terms3x3", None) or os.environ.get("SDN_CNN_TERMS")
         if t3 is None:
             t3 = (f"{cal['terms3x3']}-term (auto: 1-term vs 3-term image differed by {cal['max_abs_diff_1term_vs_3term']:.1e} <= "
                   f"{cal['bound']:.0e} on the style's first frame)" if cal and cal["terms3x3"] == 1 else
@@ -999,6 +1094,8 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
                 if probe is not None:
                     c1.record(main)
                     probe.setdefault("render_cnn", []).append((c0, c1))
+                if i == len(poses) - 1 and len(poses) >= RECHECK_MIN_FRAMES:
+                    self.recheck_cnn(net_out)        # (once per style: the adopted 3x3 rung on a pose the calibration did not see)
                 yield img[:, :, c:-c, c:-c] if c else img
         if pending is not None:
             last, pending = pending, None
@@ -1011,6 +1108,7 @@ def _render_frames(self, poses, resolution_hw=(540, 960), num_samples=24, mode="
 
 Renderer.render_frames = _render_frames
 
+RECHECK_MIN_FRAMES = 2     # trajectories at least this long re-check the adopted CNN rung on their last frame (Renderer.recheck_cnn)
 FRONT_DEFAULT = "early"
 CNN_STREAM_DEFAULT = "0"   # render CNN of frame i on its own stream beside the field kernel of frame i+1 (see _render_frames)
 CNN_AUTO_BOUND = 5e-4   # mfma_cnn: largest image difference (max abs) at which the 1-term 3x3 convolutions are accepted
@@ -1030,6 +1128,8 @@ IMAGE_AUTO_BOUND = 8e-4    # largest image error of the whole fused path vs the 
 SKY_AUTO_BOUND = 2e-4      # largest sky_c error (vs PyTorch fp32) at which the sky MLP's hidden layers run as f16 + fp6 corrections
 CAL_MAX_PIXELS = 1 << 22   # frames above this many pixels (1920x1080 is below: calibrated at its own resolution) are calibrated at a reduced resolution (same pose)
 CAL_CHUNK = 1 << 16        # rays per launch group of the fp32 field
+CAL_CROP = 256             # calibrate_one: side of the window (output pixels) the fp32 twin and the candidates are evaluated on (0: whole frame)
+CAL_CROP_FACTOR = 1.15     # ... and what a maximum measured on that window is multiplied by before it meets a bound
 MISS_COST = 0.2            # row_costs: cost of a ray that hits nothing relative to one that does (ray casting + sky MLP + CNN vs + field)
 FIELD_GATE = os.environ.get("SDN_FIELD_GATE", "1") != "0"   # (0: no field calibration -- kernel timing experiments only)
 CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (conv2a, conv2b, conv3a, conv3b)

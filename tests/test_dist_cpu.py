@@ -162,7 +162,7 @@ def _agree_worker(rank, world, port, q):
         R.dev = torch.device("cpu")
         R._fused_style = None
 
-        def calibrate_style(pose, hw, ns):
+        def calibrate_style(pose, hw, ns, more_poses=()):
             # what two ranks could measure on their frames: rank 1 sees the rung "1113" just outside the gate, rank 0 inside
             d1113 = 4.5e-4 if rank == 0 else 5.5e-4
             meas = dict(field_err={6: 6e-5 + 1e-5 * rank, 3: 5e-5}, colour_diff=5e-5, sky_err={3: 4e-6, 6: 1e-4},
@@ -196,3 +196,33 @@ def test_precision_ladder_is_agreed_over_ranks_world2():
     assert [r[1] for r in res] == ["1113", "1133"]                 # left alone, the ranks would have rendered with different precisions
     assert [r[2] for r in res] == ["1133", "1133"]                 # agreed: the rung the worst measurement allows
     assert all(abs(r[3] - 5.5e-4) < 1e-12 and abs(r[4] - 7e-5) < 1e-12 and r[5] == 2 for r in res)
+
+
+def test_band_feedback_converges_on_a_wrong_cost_model():
+    """dist.rebalance_scale: the static row-cost model is wrong by a content-dependent factor (here: the true cost of a 'ground'
+    row is 2.2x the model's in the lower third, sky rows cost 3x the model's) -- bands cut on the model are 25 % out of balance at
+    8 bands; feeding the measured band times back (what render_frame_tile_parallel(balance="feedback") does between consecutive
+    frames) brings max / mean below 1.05 within three frames, on cuts that stay multiples of 4 rows, identically on every rank
+    (a pure function of shared values)."""
+    import numpy as np
+    from scenedreamer_amd import dist as sdist
+    H, world = 2160, 8
+    rows = np.arange(H)
+    model = np.where(rows < 700, 0.2, 1.0) * 3870.0                       # Renderer.row_costs: sky rows MISS_COST, ground rows hits
+    truth = model * np.where(rows < 700, 3.0, np.where(rows > 1440, 2.2, 1.0)) * (1.0 + 0.1 * np.sin(rows / 97.0))
+    measure = lambda bands: [float(truth[a:b].sum()) + 5.0e4 for a, b in bands]     # + a per-band constant (apron rows, launches)
+    scale, hist = None, []
+    for it in range(5):
+        bands = sdist.balanced_row_bands(model * scale if scale is not None else model, world)
+        assert bands[0][0] == 0 and bands[-1][1] == H and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+        assert all(a % 4 == 0 for a, _ in bands)
+        ms = measure(bands)
+        hist.append(max(ms) / (sum(ms) / len(ms)))
+        new = sdist.rebalance_scale(model, scale, bands, ms)
+        again = sdist.rebalance_scale(model, scale, bands, list(ms))      # same inputs -> same bits (every rank computes this itself)
+        assert np.array_equal(new, again) and abs(new.mean() - 1.0) < 1e-12
+        scale = new
+    assert hist[0] > 1.2 and hist[3] < 1.05 and hist[4] < 1.05, hist
+    # garbage measurements leave the scale alone
+    s2 = sdist.rebalance_scale(model, scale, bands, [float("nan")] * world)
+    assert np.array_equal(s2, scale)

@@ -121,11 +121,11 @@ def test_minimal_apron_is_bit_identical_at_full_size(big):
 
 @pytest.mark.parametrize("hw,ns,pi", [((540, 960), 24, 4), ((1080, 1920), 40, 12)])
 def test_fused_and_unfused_frames_agree_at_full_size(big, hw, ns, pi):
-    R, scene, poses = big
     """The fused HIP frame against the reference's op sequence in fp32 ON THE GPU (torch-op sample placement with the float32
     cumsum of a GPU tensor -- how the reference's CUDA path places samples, mc_utils.py:82-151 --, HIP grid op, torch fp32 MLP and
     conv2d): the nearest stand-in for "the reference CUDA path" of the north star on this box.  Asserted < 1e-3 and RECORDED
     (gpurun_out/fused_vs_gpu_placement_<H>.json -> profiles/)."""
+    R, scene, poses = big
     import json
     import os
     a = R.render_frame(poses[pi], hw, ns, mode="fused")
@@ -197,3 +197,47 @@ def test_trajectory_to_png_and_mp4_keeps_pace(big, tmp_path):
     assert fps == 10 and len(frames) == len(sel)
     assert np.abs(frames[9].astype(np.int32) - keep[9].astype(np.int32)).mean() < 4.0      # JPEG
     assert delivered_fps > 0.5 * render_fps and delivered_fps > 15.0
+
+
+@pytest.mark.parametrize("pi", [0, 10])
+def test_colour_skipping_and_ray_blocks_change_no_bit_at_the_headline_size(big, monkeypatch, pi):
+    """Colour-branch skipping (with its ring restarts after long runs of skipped passes) and the 8 x 4-pixel ray blocks are
+    bit-tested on the 256^2 scene in tests/test_fused_gpu.py; here AT the headline size -- 2048^2 scene, the 548 x 968 window of
+    the 570 x 990 padded frame, 24 samples, pose 0 (36 % of the passes skip) and the dense pose 10 (5 %): net_out with skipping
+    on / off and with blocked / row-major ray order must be the same bits (every sample evaluated: term_eps 0, so that the
+    groups which stop together cannot differ between the two ray orders), and with the default early termination skipping
+    on / off must still be the same bits (the decision does not move a termination)."""
+    from scenedreamer_amd import fused
+    R, scene, poses = big
+    hw, ns = (540, 960), 24
+    with torch.no_grad():
+        vid, d2, rd, (H0, W0) = R.cast_rays(poses[pi], hw)
+        n = H0 * W0
+        vid, d2, rd = vid.view(n, R.M), d2.view(2, n, R.M), rd.view(n, 3)
+        sky_c, sky_avg = fused.sky_fused(R, rd)
+        win = fused.Window.crop(H0, W0, R.pad // 2 - 4)
+        assert win.blocked(0, win.n_rays) and (win.n_rays // win.cols, win.cols) == (548, 968)
+        ori = torch.as_tensor(poses[pi][0], dtype=torch.float32)
+
+        def run(skip, blocks, eps):
+            monkeypatch.setenv("SDN_RAY_BLOCKS", "1" if blocks else "0")
+            R.colour_skip, R.term_eps = skip, eps
+            try:
+                pa = torch.zeros((win.n_rays + 31) // 32, dtype=torch.uint8, device=R.dev)
+                cp = torch.zeros_like(pa)
+                out = fused.field_render(R, vid, d2, rd, ori, sky_c, sky_avg, ns, passes=pa, colour_passes=cp, window=win).clone()
+                return out, int(pa.sum(dtype=torch.int64)), int(cp.sum(dtype=torch.int64))
+            finally:
+                R.colour_skip = R.term_eps = None
+        base, p0, c0 = run(True, True, 0.0)
+        off, p1, c1 = run(False, True, 0.0)
+        rows, p2, c2 = run(True, False, 0.0)
+        # skipping really skipped; off = every pass ran its colour branch (the row-major launch forms other 32-ray groups, so it
+        # visits another number of them: only its bits are compared)
+        assert p0 == p1 and c1 == p1 and c0 < p0 and c2 < p2
+        assert torch.equal(base.view(torch.int32), off.view(torch.int32)), "colour-branch skipping changed net_out"
+        assert torch.equal(base.view(torch.int32), rows.view(torch.int32)), "blocked ray order changed net_out"
+        t_on, q0, k0 = run(True, True, None)
+        t_off, q1, k1 = run(False, True, None)
+        assert q0 == q1 and torch.equal(t_on.view(torch.int32), t_off.view(torch.int32))
+        print(f"pose {pi}: {p0} passes, colour branch on {c0} (blocked) / {c2} (row-major) of them; with termination {q0} passes, colour on {k0}; all bit-equal")
