@@ -412,7 +412,8 @@ def test_cnn_forms():
     assert form_key(1) == 1 and form_key("1111") == 1 and form_key((3, 3, 3, 3)) == 3 and form_key([1, 1, 1, 3]) == "1113"
     assert form_terms("1133") == (1, 1, 3, 3) and form_terms(3) == (3, 3, 3, 3)
     assert [form_cost(f) for f in CNN_LADDER] == sorted(form_cost(f) for f in CNN_LADDER) and CNN_LADDER[0] == 1 and CNN_LADDER[-1] == 3
-    with pytest.raises(AssertionError):
+    assert form_key("1") == 1 and form_key(" 3 ") == 3 and form_key("1113") == "1113"      # SDN_CNN_TERMS arrives as a string
+    with pytest.raises(ValueError, match="1113"):
         form_key("113")
 
 
