@@ -60,6 +60,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
 
 constexpr int HID = 256;        // hidden width (layers.py:62)
 constexpr int FEAT = 128;       // hash-grid output width: 16 levels x 8 channels
@@ -1743,7 +1744,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     // of group n+2 is issued at the start of group n and read at the start of group n+1, so its latency is never
     // waited for, and the group after the current one is always known: its first pass is prefetched during the current
     // group's last).  Groups are independent, so net_out does not depend on the schedule.
-    volatile int *flags = reinterpret_cast<volatile int *>(lds + LDS_FLAGS);
+    // The workgroup's decision words (LDS_FLAGS), accessed with explicit ds instructions: as a `volatile int *` they became FLAT
+    // loads / stores (sc0 sc1) whose 64-bit addresses hipcc kept in scratch memory and each of which it followed with
+    // s_waitcnt vmcnt(0) -- a complete drain of the weight ring's DMAs at every group start, after every pass (termination
+    // ballot) and in every colour-skip decision (seen in the ISA of rounds 4-5: 17 flat operations, 48 of the kernel's 100 B of scratch).
+#define flags_a lds_addr(lds + LDS_FLAGS)
+    auto flag_put = [&](int word, int v) { asm volatile("ds_write_b32 %0, %1" ::"v"(flags_a + 4u * (unsigned)word), "v"(v) : "memory"); };
+    auto flag_get4 = [&](int word0) -> i32x4v {     // words word0 .. word0 + 3 (16-byte aligned), landed
+        i32x4v f;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(f) : "v"(flags_a + 4u * (unsigned)word0) : "memory");
+        return f;
+    };
     int grp = blockIdx.x, grp_next = blockIdx.x + (int)gridDim.x;
     // FUSED: the first intersection of this lane's ray in group g (0 = none / no ray).  The next group's is loaded at the
     // START of the current one, so a group does not begin with an exposed round trip to memory
@@ -1777,14 +1788,15 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         // (AUX also returns the per-sample sigma / colour of rays that hit nothing -- the reference evaluates them -- so it skips no group)
         const bool any_hit = AUX ? tile_ok : __any(!(flag & 1));
         // workgroup-uniform decisions: skip the group when none of its 32 rays hits anything; everybody learns the draw
-        if (lane == 0) flags[wave] = any_hit ? 1 : 0;
-        if (threadIdx.x == 0) flags[4] = drawn;
+        if (lane == 0) flag_put(wave, any_hit ? 1 : 0);
+        if (threadIdx.x == 0) flag_put(4, drawn);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         // readfirstlane makes the decisions provably uniform: otherwise every loop-carried ring counter / pointer is
         // classified divergent, lives in VGPRs (spills!) and the DMA cannot use scalar addressing
-        const bool grp_hit = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
-        const int grp_next2 = __builtin_amdgcn_readfirstlane(flags[4]);
+        const i32x4v fh = flag_get4(0), fd = flag_get4(4);
+        const bool grp_hit = __builtin_amdgcn_readfirstlane(fh[0] | fh[1] | fh[2] | fh[3]) != 0;
+        const int grp_next2 = __builtin_amdgcn_readfirstlane(fd[0]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // the next group rewrites the flags only after everyone has read them
 
@@ -1958,10 +1970,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
                         const int wave_zero = __popcll(__ballot(zero_w));          // lanes: 2 per sample
                         // ONE barrier: flags[8..11] are written only here, and a wave reaches its next write only through the ring
                         // barriers of at least one whole layer, which nobody passes before having read these
-                        if (lane == 0) flags[8 + wave] = wave_zero;
+                        if (lane == 0) flag_put(8 + wave, wave_zero);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
-                        const int grp_zero = __builtin_amdgcn_readfirstlane(flags[8] + flags[9] + flags[10] + flags[11]);
+                        const i32x4v fz = flag_get4(8);
+                        const int grp_zero = __builtin_amdgcn_readfirstlane(fz[0] + fz[1] + fz[2] + fz[3]);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         seg_tick<DBG>(lds, 11, t_seg);
                         // Whether a pass is empty hardly depends on the depth along the rays (measured on the benchmark frames,
@@ -2097,10 +2110,11 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
             if (p.term_depth > 0.f && ch + 1 < p.nch) {
                 const bool opaque = !ray_ok || (flag & 1) || carry > p.term_depth;
                 const bool wave_done = __all(opaque);
-                if (lane == 0) flags[wave] = wave_done ? 1 : 0;
+                if (lane == 0) flag_put(wave, wave_done ? 1 : 0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                const bool grp_done = __builtin_amdgcn_readfirstlane(flags[0] & flags[1] & flags[2] & flags[3]) != 0;
+                const i32x4v ft = flag_get4(0);
+                const bool grp_done = __builtin_amdgcn_readfirstlane(ft[0] & ft[1] & ft[2] & ft[3]) != 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (grp_done) break;

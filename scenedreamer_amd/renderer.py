@@ -334,11 +334,23 @@ class Renderer:
         if crop_px is None:
             crop_px = int(os.environ.get("SDN_CAL_CROP", CAL_CROP))
         crop = self.pad // 2
+        import time as _time
+        phases, _t = {}, [None]
+
+        def tick(name):          # SDN_CAL_TIMING=1: wall clock per phase (synchronised) -> meas["timing_ms"] (tools/cal_timing.py)
+            if os.environ.get("SDN_CAL_TIMING"):
+                torch.cuda.synchronize()
+                now = _time.perf_counter()
+                if _t[0] is not None and name:
+                    phases[name] = phases.get(name, 0.0) + 1000.0 * (now - _t[0])
+                _t[0] = now
         with torch.no_grad():
+            tick(None)
             vid, d2, rd, (H0, W0) = self.cast_rays(pose, (H, W))
             n = H0 * W0
             vid, d2, rd = vid.view(n, self.M), d2.view(2, n, self.M), rd.view(n, 3)
             ori = torch.as_tensor(pose[0], dtype=torch.float32).reshape(3)
+            tick("cast rays")
             inner = (lambda im: im[:, :, crop:-crop, crop:-crop]) if crop else (lambda im: im)
             # ---- the window: where the frame's content changes most from pixel to pixel -- silhouettes, material boundaries, depth
             #      steps of the first hit (from the ray caster's output: no field evaluation needed) -- is where net_out varies most
@@ -360,6 +372,7 @@ class Renderer:
                 k = int(box.argmax())
                 r0, c0 = (k // box.shape[1]) * 8, (k % box.shape[1]) * 8
                 del g, box
+            tick("window choice")
             nc = Hc * Wc
             cut = lambda t, last: t.view(H0, W0, last)[r0:r0 + Hc, c0:c0 + Wc].reshape(nc, last).contiguous()
             if windowed:
@@ -389,11 +402,14 @@ class Renderer:
             if savg32 is None:      # whole frame (or an explicit fp6 sky): the fp32 mean over every ray
                 savg32 = (sky32_c if not windowed else self.sky_features(rd)).mean(dim=0, keepdim=True)
             skyc_c = cut_sky(sky_c)
+            tick("sky (fp32 twin on the window, 2 fused forms on the frame)")
             # ---- the fp32 twin of the window
             ref_no = torch.cat([self.field_unfused(vid_c[r:r + CAL_CHUNK], d2_c[:, r:r + CAL_CHUNK].contiguous(), rd_c[r:r + CAL_CHUNK], ori_dev,
                                                    sky32_c[r:r + CAL_CHUNK], savg32, num_samples, placement="kernel")
                                 for r in range(0, nc, CAL_CHUNK)], dim=0)
+            tick("fp32 field twin")
             ref_img = inner(self.render_cnn(ref_no.view(1, Hc, Wc, 64)))
+            tick("fp32 CNN twin")
             # ---- the fused field on the window's rays
             no = {}
             try:
@@ -409,6 +425,7 @@ class Renderer:
                 raw["colour_diff"] = float((no[6] - no[3]).abs().max())
                 meas["colour_diff"] = raw["colour_diff"] * k_ev
             ct = explicit_ct if explicit_ct is not None else (6 if meas["colour_diff"] <= COLOUR_AUTO_BOUND else 3)
+            tick("fused field, 2 colour forms")
             # ---- the render CNN on the chosen field's output
             from .cnn import CNN_LADDER, form_key
             explicit_t = getattr(self, "cnn_terms3x3", None)
@@ -426,6 +443,7 @@ class Renderer:
                 raw["cnn_diffs"] = {t: float((imgs[t] - imgs[3]).abs().max()) for t in CNN_LADDER if t != 3}
                 meas["cnn_diffs"] = {t: e * k_ev for t, e in raw["cnn_diffs"].items()}
                 meas["cnn_diff"] = meas["cnn_diffs"][1]
+            tick("MFMA CNN rungs")
             if windowed:        # (a window's activation planes are not the frame's: drop them, the packed weights stay)
                 for c in self.__dict__.get("_mfma_cnns", {}).values():
                     c._planes.pop((Hc, Wc), None)
@@ -433,6 +451,8 @@ class Renderer:
                     frame=f"{W}x{H} (+{self.pad}-px apron), {num_samples} samples/ray" +
                           (f"; window {Wc - 2 * crop}x{Hc - 2 * crop} at ({r0},{c0}), maxima x {CAL_CROP_FACTOR}" if windowed else ""),
                     window=([r0, c0, Hc, Wc] if windowed else None), raw=raw if windowed else None)
+        if phases:
+            meas["timing_ms"] = phases
         return meas
 
     def adopt_precision(self, meas):
@@ -1136,7 +1156,7 @@ CNN_HALO = 4   # receptive-field radius of RenderCNN: four 3x3 convolutions (con
 
 
 L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md: 4 MiB per XCD, ~34.5 TB/s aggregate
-PMC_PROFILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
+PMC_PROFILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")   # newest first
 
 
 def _profiled_traffic():
