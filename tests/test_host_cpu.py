@@ -643,3 +643,17 @@ def test_stdout_guard_leaves_exactly_one_line_on_stdout():
     assert r.returncode == 0, r.stderr
     assert r.stdout == '{"value": 1}\n'
     assert "Rendering frame 1" in r.stderr and "library chatter" in r.stderr and "child chatter" in r.stderr
+
+
+def test_busiest_window_equals_pooling():
+    """renderer._busiest_window (summed-area table) picks the window a dense average pooling would, ragged sizes included."""
+    import torch
+    import torch.nn.functional as F
+    from scenedreamer_amd.renderer import _busiest_window
+    g0 = torch.Generator().manual_seed(3)
+    for (H, W, Hc, Wc) in ((570, 990, 286, 286), (131, 77, 40, 77), (64, 64, 64, 64), (301, 415, 264, 264)):
+        g = torch.rand(H, W, generator=g0)
+        g[H // 3:H // 3 + 9, W // 2:W // 2 + 11] += 2.0
+        box = F.avg_pool2d(g[None, None].double(), (Hc, Wc), stride=8)[0, 0]
+        k = int(box.argmax())
+        assert _busiest_window(g, Hc, Wc) == ((k // box.shape[1]) * 8, (k % box.shape[1]) * 8)
