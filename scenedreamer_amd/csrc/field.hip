@@ -855,6 +855,22 @@ __device__ __forceinline__ const char *ring_lane_src(const char *slot_base, cons
     return reinterpret_cast<const char *>(((size_t)hi << 32) | lo);
 }
 
+// r.lds_lane again, from nothing but the lane id.  It is the one per-lane value every unit of every layer needs (fragment reads, DMA
+// source addresses), so it lives for the whole kernel -- and under the field kernel's register pressure hipcc parks it in scratch
+// memory at three places; the reloads are vector-memory loads, and from then on its waitcnt pass puts `s_waitcnt vmcnt(0)` in front
+// of the first use on every path a reload may have come from: right behind the hand-counted `vmcnt(8)` + barrier at the entry of
+// EVERY layer (seen in the ISA of rounds 4-6: six full drains of the weight ring's DMAs per pass).  Redefining the value at each
+// layer entry (three VALU instructions the compiler cannot hoist) ends the live range there: nothing to reload, nothing to wait for.
+__device__ __forceinline__ void ring_refresh_lane(char *lds, Ring &r) {
+    unsigned int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\t"
+                 "v_mbcnt_hi_u32_b32 %0, -1, %0\n\t"
+                 "v_lshl_add_u32 %0, %0, 4, %1"
+                 : "=&v"(l)
+                 : "s"((unsigned)(size_t)(const lds_char *)(lds + LDS_RING)));
+    r.lds_lane = l;
+}
+
 template <int K>
 __device__ __forceinline__ void ring_dma(const char *lane_src, char *dbase) {
     // address = this lane's source address of the slot (+ 4 KiB for the second group of four pieces) + immediate; the LDS
@@ -1330,6 +1346,7 @@ __device__ __forceinline__ void layer8(char *lds, Ring &r, half8 (&bh)[16], half
                                        const float *bias, const float *bias_pend, const float *wsig, int h, float &part,
                                        float k_own = 1.f, float k_pend = 1.f) {
     LayerState st;
+    ring_refresh_lane(lds, r);
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
     layer8_fetch<DBG, NS, HAS_PEND, SIG_PEND, SIG_OWN, 0, layer8_spread(NS, HAS_PEND, TERMS) && !(DBG & 16)>(bias, bias_pend, wsig, h, st);
@@ -1538,6 +1555,7 @@ __device__ __forceinline__ void layer8x(char *lds, Ring &r, half8 (&bh)[16], hal
                                         const float *bias, const float *bias_pend, const float *wsig, int h, float &part,
                                         float k_own = 1.f, float k_pend = 1.f) {
     LayerState st;
+    ring_refresh_lane(lds, r);
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
     layer8_fetch<DBG, 16, true, SIG_PEND, SIG_OWN, 0, KIND == 0>(bias, bias_pend, wsig, h, st);
@@ -1644,6 +1662,7 @@ template <int DBG>
 __device__ __forceinline__ void layer_out(char *lds, Ring &r, half8 (&bh)[16], half8 (&bl)[16], const f32x16 (&acc)[8],
                                           f32x16 (&col)[2], const float *bias_pend, int h, float &part) {
     OutState st;
+    ring_refresh_lane(lds, r);
     st.pos_cur = ring_acquire<DBG>(lds, r);
     st.pos_nxt = (st.pos_cur + 1) & (NSLOT - 1);
     out_fetch<DBG, 0>(bias_pend, h, st);
