@@ -210,7 +210,11 @@ int sdn_field_pack_weights_mx(const float *w1, const float *const *wh5_host, con
  *   so a group's all-or-nothing savings (colour-branch skipping, early termination) apply more often; per-ray results are the
  *   same bits, the per-ray outputs and inputs that are not read through the window (net_out, the sdn_field_aux arrays, u_dev) stay
  *   in the window's row-major order; `passes` / `colour_passes` then count per block.  sdn_field_encode and sdn_field_mlp of one
- *   frame must be given the same value. */
+ *   frame must be given the same value.
+ *   blocked == 2 (sdn_field_render only; ray0 = 0, n_rays = rows x cols, ANY rows / cols): the same block order over the
+ *   ceil(cols / 8) x ceil(rows / 4) block grid that covers the window; block positions outside the window are no rays.  `passes` /
+ *   `colour_passes` then hold ceil(cols / 8) * ceil(rows / 4) entries (>= ceil(n_rays / 32)); u_dev must be NULL.  With whole
+ *   blocks it is the same launch as blocked == 1. */
 int sdn_field_encode(const int32_t *voxel_id, const float *depth2, const float *raydirs, const uint8_t *lut1024,
                      const float *table3, uint32_t table_rows, const float *scales_dev, const float *genc_host,
                      const float *cam_ori_host, const float *voxel_dims_host, const float *lin_dev, const float *u_dev,

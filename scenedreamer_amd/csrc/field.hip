@@ -112,20 +112,28 @@ constexpr int C_TOTAL = C_SKY_AVG + OUTC;
 // agree more often: measured on the benchmark frames 36 -> 40 %, 34 -> 40 %, 23 -> 32 % of the passes without colour branch
 // (tools/dbg_sigma_stats.py).  A wave still reads 8 consecutive rays of a row (the same coalescing), rays are independent
 // (net_out is the same bits per ray, only its per-group statistics move), the per-ray OUTPUTS stay in the window's row-major
-// order (out_row).  The host sets it when the launch covers a whole window of 8k columns x 4m rows.
+// order (out_row).  The host sets it when the launch covers a whole window of 8k columns x 4m rows -- or (sdn_field_render only,
+// `rows` > 0) a whole window of ANY size: the block grid is ceil(cols / 8) x ceil(rows / 4), the launch has that many 32-ray groups,
+// and the block positions outside the window are no rays (`valid`): the reference's 570 x 990 padded frame (990 = 8 * 123 + 6)
+// takes the blocked order that way.
 struct RayWindow {
     int32_t n_src;             // rays in the source arrays (stride of depth2's two planes)
     int32_t pitch, first, cols, ray0;
-    int32_t tiled_bx;          // 0: row-major ray order; else 8 x 4 pixel blocks, this many per block row (= cols / 8)
-    // window-local pixel index (row-major) of launch-local ray r
+    int32_t tiled_bx;          // 0: row-major ray order; else 8 x 4 pixel blocks, this many per block row (= ceil(cols / 8))
+    int32_t rows;              // tiled + ragged: rows of the window (block positions at x >= cols or y >= rows are no rays); else 0
+    // window-local pixel index (row-major) of launch-local ray r; -1: a block position outside a ragged window
     __device__ __forceinline__ int pix(int r) const {
         const int w = ray0 + r;
         if (tiled_bx == 0) return w;
         const int b = w >> 5, by = b / tiled_bx, bxi = b - by * tiled_bx;
-        return (4 * by + ((w & 31) >> 3)) * cols + 8 * bxi + (w & 7);
+        const int y = 4 * by + ((w & 31) >> 3), x = 8 * bxi + (w & 7);
+        if (rows > 0 && (x >= cols || y >= rows)) return -1;
+        return y * cols + x;
     }
+    __device__ __forceinline__ bool valid(int r) const { return rows == 0 || pix(r) >= 0; }
     __device__ __forceinline__ int src(int r) const {
-        const int q = pix(r);
+        int q = pix(r);
+        q = q < 0 ? 0 : q;     // (a position outside the window reads the window's first ray: a valid address, discarded by the caller)
         return cols > 0 ? first + (q / cols) * pitch + (q % cols) : q;
     }
     // row of launch-local ray r in the launch's per-ray outputs / inputs that are NOT read through the window (net_out, the
@@ -667,7 +675,7 @@ __global__ __launch_bounds__(256, SDN_ENC_OCC) void encode_kernel(const EncParam
     if (tile >= p.n_tiles) return;
     const int h = lane >> 5, j = lane & 31;
     const int ray = tile * RAYS_PER_TILE + (j >> 2);
-    const bool ray_ok = ray < p.R;
+    const bool ray_ok = ray < p.R && p.win.valid(ray);
     const int rl = ray_ok ? ray : p.R - 1;      // local ray (index into u / rayflag)
     const int rr = p.win.src(rl);               // the same ray in the source arrays
 
@@ -1779,7 +1787,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     // START of the current one, so a group does not begin with an exposed round trip to memory
     auto first_vox = [&](int g) -> int {
         const int t = g * 4 + wave, ry = t * RAYS_PER_TILE + (j >> 2);
-        if (!(g < n_groups && t < p.n_tiles && ry < p.R)) return 0;
+        if (!(g < n_groups && t < p.n_tiles && ry < p.R && enc.win.valid(ry))) return 0;
         return enc.voxel_id[(size_t)enc.win.src(ry) * enc.M];
     };
     int vox_cur = 0;
@@ -1791,7 +1799,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
         const int tile_s = grp * 4 + r.wave;              // the same as scalars (r.wave went through readfirstlane)
         const bool tile_ok_s = tile_s < p.n_tiles;
         const int ray = tile * RAYS_PER_TILE + (j >> 2);
-        const bool ray_ok = tile_ok && ray < p.R;
+        const bool ray_ok = tile_ok && ray < p.R && (!FUSED || p.win.valid(ray));
         const int rl = ray_ok ? ray : p.R - 1;            // FUSED: local ray / the same ray in the frame-wide arrays
         const int rr = FUSED ? enc.win.src(rl) : 0;
         uint8_t flag;                                      // bit 0 sky_only, bit 1 nosky (FUSED: bit 1 is known at the group's end)
@@ -3005,8 +3013,12 @@ size_t sdn_field_aux_elems(int32_t n_rays, int32_t num_samples) {
 }
 
 // window_host: NULL, or {n_src, pitch, first, cols, ray0} (see RayWindow)
-static int set_window(RayWindow &w, const int32_t *window_host, int32_t n_rays, const char *who) {
+// launch_rays (sdn_field_render only): receives the rays of the launch -- n_rays, or, for a ragged blocked window
+// (window_host[5] == 2), 32 x the blocks of its ceil(cols / 8) x ceil(rows / 4) grid
+static int set_window(RayWindow &w, const int32_t *window_host, int32_t n_rays, const char *who, int32_t *launch_rays = nullptr) {
     w.tiled_bx = 0;
+    w.rows = 0;
+    if (launch_rays) *launch_rays = n_rays;
     if (window_host == nullptr) {
         w.n_src = n_rays; w.pitch = 0; w.first = 0; w.cols = 0; w.ray0 = 0;
         return 0;
@@ -3014,7 +3026,19 @@ static int set_window(RayWindow &w, const int32_t *window_host, int32_t n_rays, 
     w.n_src = window_host[0]; w.pitch = window_host[1]; w.first = window_host[2]; w.cols = window_host[3]; w.ray0 = window_host[4];
     if (w.n_src <= 0 || w.cols < 0 || w.ray0 < 0 || w.first < 0 || w.pitch < 0)
         return sdn::fail(SDN_ERR_INVALID, "%s: bad ray window", who);
-    if (window_host[5]) {   // 8 x 4 pixel blocks: the launch is the whole window, whole blocks only
+    if (window_host[5] == 2) {   // 8 x 4 pixel blocks over a whole window of any size: positions outside it are no rays
+        if (!launch_rays) return sdn::fail(SDN_ERR_UNSUPPORTED, "%s: the ragged blocked ray order exists for sdn_field_render only", who);
+        if (!(w.cols > 0 && w.ray0 == 0 && n_rays % w.cols == 0))
+            return sdn::fail(SDN_ERR_INVALID, "%s: the blocked ray order needs a whole window (ray0 = 0, n_rays = rows x cols)", who);
+        const int rows = n_rays / w.cols;
+        w.tiled_bx = (w.cols + 7) / 8;
+        if (w.cols % 8 || rows % 4) {
+            w.rows = rows;
+            const long lr = (long)w.tiled_bx * ((rows + 3) / 4) * 32;
+            if (lr >= ((long)1 << 31)) return sdn::fail(SDN_ERR_INVALID, "%s: window too large", who);
+            *launch_rays = (int32_t)lr;
+        }
+    } else if (window_host[5]) {   // 8 x 4 pixel blocks: the launch is the whole window, whole blocks only
         if (!(w.cols > 0 && w.cols % 8 == 0 && w.ray0 == 0 && n_rays % w.cols == 0 && (n_rays / w.cols) % 4 == 0))
             return sdn::fail(SDN_ERR_INVALID, "%s: the blocked ray order needs a whole window of 8k columns x 4m rows (ray0 = 0)", who);
         w.tiled_bx = w.cols / 8;
@@ -3091,7 +3115,7 @@ int sdn_sample_depth(const float *depth2, const float *lin_dev, const float *u_d
 
 static int fill_mlp(MlpParams &p, const char *who, const void *packed, const float *consts, const float *sky_c, float *net_out,
                     int32_t n_rays, int32_t num_samples, int32_t colour_terms, float term_eps, uint8_t *passes, const int32_t *window_host,
-                    const float *sky_avg, int32_t *ticket) {
+                    const float *sky_avg, int32_t *ticket, int32_t *launch_rays = nullptr) {
     if (!(packed && consts && sky_c && net_out)) return sdn::fail(SDN_ERR_INVALID, "%s: null pointer", who);
     if (!(n_rays > 0 && num_samples > 0)) return sdn::fail(SDN_ERR_INVALID, "%s: empty frame", who);
     if (!(colour_terms == 2 || colour_terms == 3 || colour_terms == 6)) return sdn::fail(SDN_ERR_INVALID, "%s: colour_terms must be 2, 3 or 6", who);
@@ -3105,7 +3129,7 @@ static int fill_mlp(MlpParams &p, const char *who, const void *packed, const flo
     p.wpk = (const half8 *)packed;
     p.consts = consts; p.sky_c = sky_c; p.net_out = net_out;
     p.sky_avg = sky_avg; p.ticket = ticket;
-    if (int rc = set_window(p.win, window_host, n_rays, who)) return rc;
+    if (int rc = set_window(p.win, window_host, n_rays, who, launch_rays)) return rc;
     p.R = n_rays; p.ns = num_samples;
     p.nch = sdn::div_up(num_samples, SAMP_PER_STEP);
     p.n_tiles = sdn::div_up(n_rays, RAYS_PER_TILE);
@@ -3176,14 +3200,20 @@ int sdn_field_render(const int32_t *voxel_id, const float *depth2, const float *
     SDN_REQUIRE(!(want_aux && term_eps > 0.f), "sdn_field_render: the per-sample outputs need term_eps = 0 (every pass must run)");
     static const float zero3[3] = {0.f, 0.f, 0.f};
     if (cam_ori_dev && !cam_ori_host) cam_ori_host = zero3;
+    int32_t launch_rays = n_rays;
     if (int rc = fill_mlp(p, "sdn_field_render", packed, consts, sky_c, net_out, n_rays, num_samples, colour_terms, term_eps, passes,
-                          window_host, sky_avg, ticket))
+                          window_host, sky_avg, ticket, &launch_rays))
         return rc;
     if (int rc = fill_enc(p.enc, "sdn_field_render", voxel_id, depth2, raydirs, lut1024, table3, table_rows, scales_dev, genc_host,
                           cam_ori_host, voxel_dims_host, lin_dev, u_dev, n_rays, max_blocks, num_samples, sample_depth, dists_scale,
                           strat_division))
         return rc;
     p.enc.win = p.win;
+    if (launch_rays != n_rays) {   // ragged blocked window: the launch walks the whole block grid (the extra positions are no rays)
+        SDN_REQUIRE(u_dev == nullptr, "sdn_field_render: stochastic sampling with the ragged blocked order is not supported");
+        p.R = p.enc.R = launch_rays;
+        p.n_tiles = p.enc.n_tiles = launch_rays / RAYS_PER_TILE;
+    }
     p.cam_ori_dev = cam_ori_dev;
     if (want_aux) {
         p.w_out = aux->weights; p.depth_out = aux->depth; p.sig_out = aux->sigma; p.col_out = aux->colour;
@@ -3222,7 +3252,7 @@ int sdn_render_mlp(const float *x, const uint8_t *label, const void *packed, con
     p.R = (int32_t)n_rows; p.ns = 32; p.nch = 8;
     p.n_tiles = (int32_t)((n_rows + 255) / 256);
     p.term_depth = 0.f; p.passes = nullptr;
-    p.win.n_src = p.R; p.win.pitch = 0; p.win.first = 0; p.win.cols = 0; p.win.ray0 = 0; p.win.tiled_bx = 0;
+    p.win.n_src = p.R; p.win.pitch = 0; p.win.first = 0; p.win.cols = 0; p.win.ray0 = 0; p.win.tiled_bx = 0; p.win.rows = 0;
     p.sky_avg = nullptr; p.ticket = ticket;
     p.cam_ori_dev = nullptr; p.w_out = nullptr; p.depth_out = nullptr; p.sigma_out = sigma;
     p.sig_out = nullptr; p.col_out = nullptr; p.skyb_out = nullptr; p.nosky_out = nullptr;

@@ -239,7 +239,7 @@ class GeneratorBinding:
             return fr["net_out"]
         H0, W0 = win.n_src // win.pitch, win.pitch
         net_out = fused.field_render(self.B, bases[0], bases[1], bases[2], cam_ori_t, last["sky_c"], sky_avg, ns,
-                                     window=fused.Window(win.n_src))
+                                     window=fused.Window.crop(H0, W0, 0))     # the whole frame as a window: 8 x 4-pixel ray blocks (ragged: 990 columns)
         self._frame = dict(last=last, cam=cam_ori_t, sky_avg=sky_avg, key=key, net_out=net_out.view(1, H0, W0, 64), img=None, raw=None,
                            keep=views)
         self.stats["frames_coalesced"] += 1

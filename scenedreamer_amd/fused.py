@@ -32,29 +32,49 @@ class Window:
         """The H0 x W0 frame without its outer o rows / columns."""
         return cls(H0 * W0, W0, o * W0 + o, H0 - 2 * o, W0 - 2 * o)
 
-    def blocked(self, ray0=0, n_rays=None):
+    def blocked(self, ray0=0, n_rays=None, ragged=False):
         """Whether a launch over this window orders its rays in 8 x 4 pixel blocks (csrc/field.hip RayWindow): the launch is the
-        whole window, of 8k columns x 4m rows.  SDN_RAY_BLOCKS=0 keeps the row-major order (A/B)."""
+        whole window, of 8k columns x 4m rows -- or, with ragged=True (sdn_field_render only), of any size: the block grid then
+        covers the window and the positions outside it are no rays.  SDN_RAY_BLOCKS=0 keeps the row-major order (A/B)."""
         if not self.cols or ray0 or (n_rays is not None and n_rays != self.n_rays) or os.environ.get("SDN_RAY_BLOCKS", "1") in ("0", ""):
             return False
         rows = self.n_rays // self.cols
-        return self.cols % 8 == 0 and rows % 4 == 0 and rows * self.cols == self.n_rays
+        if rows * self.cols != self.n_rays:
+            return False
+        return ragged or (self.cols % 8 == 0 and rows % 4 == 0)
 
-    def groups(self, per_ray):
+    def n_groups(self, ragged=False):
+        """32-ray groups of a whole-window launch (the length of its `passes` / `colour_passes` arrays)."""
+        if self.blocked(0, self.n_rays, ragged):
+            rows = self.n_rays // self.cols
+            return -(-self.cols // 8) * -(-rows // 4)
+        return (self.n_rays + 31) // 32
+
+    def groups(self, per_ray, ragged=False):
         """per_ray [n_rays, ...] (window row-major) -> [n_groups, 32, ...]: the rays of every 32-ray group of a whole-window launch
-        in the launch's ray order (padding rays: zeros)."""
+        in the launch's ray order (padding rays / block positions outside a ragged window: zeros)."""
         n = self.n_rays
-        if self.blocked(0, n):
+        if self.blocked(0, n, ragged):
             rows = n // self.cols
-            v = per_ray.reshape(rows // 4, 4, self.cols // 8, 8, *per_ray.shape[1:])
+            R4, C8 = -(-rows // 4) * 4, -(-self.cols // 8) * 8
+            v = per_ray.reshape(rows, self.cols, *per_ray.shape[1:])
+            if (R4, C8) != (rows, self.cols):
+                full = per_ray.new_zeros((R4, C8) + tuple(per_ray.shape[1:]))
+                full[:rows, :self.cols] = v
+                v = full
+            v = v.reshape(R4 // 4, 4, C8 // 8, 8, *per_ray.shape[1:])
             return v.transpose(1, 2).reshape(-1, 32, *per_ray.shape[1:])
         pad = (-n) % 32
         if pad:
             per_ray = torch.cat([per_ray, per_ray.new_zeros((pad,) + tuple(per_ray.shape[1:]))], dim=0)
         return per_ray.reshape(-1, 32, *per_ray.shape[1:])
 
-    def host(self, ray0=0, n_rays=None):
-        return _i6(self.n_src, self.pitch, self.first, self.cols, int(ray0), 1 if self.blocked(ray0, n_rays) else 0)
+    def host(self, ray0=0, n_rays=None, ragged=False):
+        mode = 0
+        if self.blocked(ray0, n_rays, ragged):
+            rows = self.n_rays // self.cols
+            mode = 1 if (self.cols % 8 == 0 and rows % 4 == 0) else 2
+        return _i6(self.n_src, self.pitch, self.first, self.cols, int(ray0), mode)
 
 
 def _lib():
@@ -343,6 +363,9 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
         for k in want:
             aux[k] = torch.empty(shapes[k][0], dtype=shapes[k][1], device=R.dev)     # (with aux the kernel visits every ray and sample)
         aux_c = capi.FieldAux(**{k: aux[k].data_ptr() for k in want})
+    # ray order: 8 x 4 pixel blocks whenever the launch is a whole window -- also a ragged one (990 columns: the reference's padded
+    # frame), unless the caller's per-group arrays are sized for the row-major groups or the sampling is stochastic
+    ragged = u is None and all(t is None or t.numel() >= window.n_groups(ragged=True) for t in (passes, colour_passes))
     skip = colour_skip(R)
     if colour_passes is not None or not skip:
         aux_c = aux_c or capi.FieldAux()
@@ -354,7 +377,7 @@ def field_render(R, vid, d2, rd, cam_ori, sky_c, sky_avg, ns, passes=None, u=Non
                                      sc["dims"].ctypes.data, lin.data_ptr(), u.data_ptr() if u is not None else None, n_rays, R.M,
                                      ns, R.sample_depth, R.dists_scale, st["packed_mx" if ct == 6 else "packed"].data_ptr(),
                                      st["consts"].data_ptr(), p_sky, sky_avg.data_ptr(), net_out.data_ptr(), ct, eps,
-                                     passes.data_ptr() if passes is not None else None, 0, window.host(0, n_rays),
+                                     passes.data_ptr() if passes is not None else None, 0, window.host(0, n_rays, ragged),
                                      {"reciprocal": 0, "ieee": 1}[division], st["ticket"].data_ptr(),
                                      ori_dev.data_ptr() if ori_dev is not None else None,
                                      ctypes.byref(aux_c) if aux_c is not None else None, _stream(R.dev))

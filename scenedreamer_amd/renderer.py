@@ -692,7 +692,7 @@ class Renderer:
                 vid, d2, rd, (H0, W0) = self.cast_rays(pose, resolution_hw)
                 hit = (vid.view(H0, W0, self.M)[o:H0 - o, o:W0 - o, 0] != 0).reshape(-1)
                 n = hit.numel()
-                g = fused.Window.crop(H0, W0, o).groups(hit).any(dim=1)          # the 32-ray groups as the launch forms them
+                g = fused.Window.crop(H0, W0, o).groups(hit, ragged=True).any(dim=1)          # the 32-ray groups as the launch forms them
                 B += n * num_samples
                 hits += float(hit.float().mean())
                 groups += float(g.float().mean())
@@ -701,7 +701,7 @@ class Renderer:
                     v, d, r = vid.view(n0, self.M), d2.view(2, n0, self.M), rd.view(n0, 3)
                     sky_c, sky_avg = fused.sky_fused(self, r)
                     win = fused.Window.crop(H0, W0, o)
-                    pa = torch.zeros((win.n_rays + 31) // 32, dtype=torch.uint8, device=self.dev)
+                    pa = torch.zeros(win.n_groups(ragged=True), dtype=torch.uint8, device=self.dev)
                     cp = torch.zeros_like(pa)
                     fused.field_render(self, v, d, r, torch.as_tensor(pose[0], dtype=torch.float32), sky_c, sky_avg, num_samples,
                                        passes=pa, window=win, colour_passes=cp)
@@ -942,6 +942,9 @@ class Renderer:
                 o = crop - CNN_HALO
                 window = fused.Window.crop(Hp, Wp, o)
                 Hp, Wp, crop = Hp - 2 * o, Wp - 2 * o, CNN_HALO
+            elif mode == "fused":       # the whole padded frame, as a window too: its launch takes the 8 x 4-pixel ray blocks
+                from . import fused
+                window = fused.Window.crop(Hp, Wp, 0)
             if mode == "unfused":
                 outs = []
                 for r0 in range(0, R, ray_chunk):

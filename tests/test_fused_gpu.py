@@ -392,6 +392,52 @@ def test_blocked_ray_order_changes_no_bit(renderer, monkeypatch):
             renderer.set_precision()
 
 
+def test_ragged_blocked_ray_order_changes_no_bit(renderer, monkeypatch):
+    """sdn_field_render on a whole window that is NOT whole 8 x 4 blocks (the frame itself: 102 x 134; a 82 x 114 crop; a 5 x 9 sliver):
+    `window_host[5] == 2` walks the covering block grid, positions outside the window are no rays.  net_out, the per-sample outputs
+    and nosky are the same bits as in row-major order (every sample evaluated); the per-group pass counters have one entry per
+    block; a caller whose `passes` array is sized for row-major groups keeps the row-major order."""
+    from scenedreamer_amd import fused
+    renderer.set_style_code(golden("field_a.npz")["z"])
+    pose, vid, d2, rd, H0, W0 = _frame(renderer)
+    ns = 12
+    ori = torch.as_tensor(pose[0], dtype=torch.float32)
+    try:
+        renderer.set_precision(term_eps=0.0)
+        with torch.no_grad():
+            sky_c, sky_avg = fused.sky_fused(renderer, rd)
+            for win in (fused.Window.crop(H0, W0, 0), fused.Window.crop(H0, W0, 10), fused.Window(H0 * W0, W0, 40 * W0 + 60, 5, 9)):
+                rows = win.n_rays // win.cols
+                assert not win.blocked(0, win.n_rays) and win.blocked(0, win.n_rays, True) and (rows % 4 or win.cols % 8)
+                monkeypatch.setenv("SDN_RAY_BLOCKS", "0")
+                ref = fused.field_render(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win).clone()
+                aux0 = {"weights": None, "sigma": None, "nosky": None, "colour": None}
+                fused.field_render(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win, aux=aux0)
+                monkeypatch.setenv("SDN_RAY_BLOCKS", "1")
+                pa = torch.zeros(win.n_groups(True), dtype=torch.uint8, device="cuda")
+                cp = torch.zeros_like(pa)
+                got = fused.field_render(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win, passes=pa, colour_passes=cp)
+                assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (rows, win.cols)
+                aux1 = {"weights": None, "sigma": None, "nosky": None, "colour": None}
+                fused.field_render(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win, aux=aux1)
+                for k in aux0:
+                    assert torch.equal(aux0[k], aux1[k]), k
+                # the counters are per block: a block is visited iff one of its rays hits, and then goes through every pass
+                hit = (vid.view(H0, W0, -1)[..., 0] != 0).reshape(-1)
+                first, pitch = win.first, win.pitch
+                yy, xx = torch.meshgrid(torch.arange(rows, device="cuda"), torch.arange(win.cols, device="cuda"), indexing="ij")
+                hit_w = hit[(first + yy * pitch + xx).reshape(-1)]
+                visited = win.groups(hit_w, ragged=True).any(dim=1)
+                assert torch.equal(pa > 0, visited) and bool((pa[visited] == -(-ns // 4)).all()) and bool((cp <= pa).all())
+                # a `passes` array sized for the row-major groups: the launch stays row-major (and is still the same bits)
+                small = torch.zeros((win.n_rays + 31) // 32, dtype=torch.uint8, device="cuda")
+                if small.numel() < win.n_groups(True):
+                    again = fused.field_render(renderer, vid, d2, rd, ori, sky_c, sky_avg, ns, window=win, passes=small)
+                    assert torch.equal(again, ref)
+    finally:
+        renderer.set_precision()
+
+
 # ---------------------------------------------------------------------------------------------------- MX fp6 colour layers
 def test_mx_fp6_hardware_facts():
     """tools/mx_probe (built by __graft_entry__.build): element order / scale semantics / rounding of the fp6 conversions and

@@ -507,6 +507,34 @@ def test_blocked_ray_order_host_side():
     assert all(fused.Window((b[1] - b[0] + 30) * 3870, 3870, 11 * 3870 + 11, b[1] - b[0] + 8, 3848).blocked(0) for b in bands)
 
 
+def test_ragged_blocked_ray_order_host_side():
+    """A whole window of ANY size (the reference's 570 x 990 padded frame: 990 = 8 * 123 + 6) takes the blocked order in
+    sdn_field_render (`window_host[5] == 2`): the block grid covers the window, positions outside it are no rays.  The host's
+    regrouping against the kernel's index formula (RayWindow::pix with `rows` > 0), the group count, and that only
+    field_render's callers opt in (the two-kernel launches keep whole blocks only)."""
+    import torch
+    from scenedreamer_amd import fused
+    for rows, cols in ((82, 114), (570, 990), (5, 9), (4, 8)):
+        win = fused.Window(rows * cols + 17, cols, 3, rows, cols)
+        whole = cols % 8 == 0 and rows % 4 == 0
+        assert win.blocked(0, win.n_rays) == whole and win.blocked(0, win.n_rays, ragged=True)
+        assert list(win.host(0, win.n_rays))[5] == (1 if whole else 0) and list(win.host(0, win.n_rays, True))[5] == (1 if whole else 2)
+        bx, by = -(-cols // 8), -(-rows // 4)
+        assert win.n_groups(True) == bx * by >= (win.n_rays + 31) // 32 and win.n_groups() == ((bx * by) if whole else (win.n_rays + 31) // 32)
+
+        def pix(r):          # RayWindow::pix, tiled_bx = ceil(cols / 8), rows > 0
+            b, within = r >> 5, r & 31
+            byi, bxi = divmod(b, bx)
+            y, x = 4 * byi + (within >> 3), 8 * bxi + (within & 7)
+            return y * cols + x if (x < cols and y < rows) else -1
+        g = win.groups(torch.arange(win.n_rays) + 1, ragged=True) - 1          # (-1: a block position outside the window)
+        want = torch.tensor([pix(r) for r in range(32 * bx * by)]).view(-1, 32)
+        assert torch.equal(g, want)
+        inside = g[g >= 0]
+        assert sorted(inside.tolist()) == list(range(win.n_rays))               # every pixel of the window exactly once
+    assert not fused.Window(1000).blocked(0, None, True)                        # no window structure: nothing to block
+
+
 def test_weight_ring_protocol_with_restarts():
     """A model of field_kernel's LDS weight ring (csrc/field.hip: Ring, ring_acquire, ring_restart): 4 positions, the DMA runs 3 slots
     ahead, a pass streams 46 slots (fc_1: 4, fc_2..fc_6: 8 each, fc_out_c: 2) -- or only the first 28 when its colour branch is
