@@ -1768,9 +1768,13 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel(const MlpParams p) {
     const int n_groups = (p.n_tiles + 3) >> 2;
     // Group schedule.  Static: workgroup b takes groups b, b + G, b + 2G, ... (G = gridDim.x).  With a ticket counter the
     // first TWO rounds are static and every later group is drawn from the counter one group AHEAD of its use (the draw
-    // of group n+2 is issued at the start of group n and read at the start of group n+1, so its latency is never
-    // waited for, and the group after the current one is always known: its first pass is prefetched during the current
-    // group's last).  Groups are independent, so net_out does not depend on the schedule.
+    // of group n+2 is issued at the start of group n, so the group after the current one is always known: its first pass
+    // is prefetched during the current group's last).  Groups are independent, so net_out does not depend on the schedule.
+    // (The atomic's round trip IS waited for at the group's start: hipcc consumes an atomic's result at once -- `vmcnt(0)`
+    // behind it, once per group, <= 0.6 % of a group's time.  Keeping the draw pending for one more group was tried in
+    // round 6: the result is then a loop-carried value, which hipcc copies into its carrier register right behind the
+    // atomic, with the same wait; returning it into a reserved physical register is what the AGPR prefetch of the
+    // two-kernel form does, and is not worth a second such contract here.)
     // The workgroup's decision words (LDS_FLAGS), accessed with explicit ds instructions: as a `volatile int *` they became FLAT
     // loads / stores (sc0 sc1) whose 64-bit addresses hipcc kept in scratch memory and each of which it followed with
     // s_waitcnt vmcnt(0) -- a complete drain of the weight ring's DMAs at every group start, after every pass (termination
