@@ -271,3 +271,39 @@ def test_bench_py_multi_rank_path_two_ranks_on_one_gpu(bench_mode):
     if bench_mode == "frames":
         assert full["broadcast"]["scene_volume_bytes"] > 0 and "cpu_baseline" not in d      # compact volume; no CPU leg at N > 1
         assert d["broadcast_s"] > 0
+
+
+def test_bench_py_single_gpu_stdout_is_one_small_json_line():
+    """The failure of round 5, end to end: `bench.py` with EVERY leg on (CPU baseline, floor / style-cost records, the unmodified
+    reference loop with its own "Rendering frame ..." prints, early-termination record) must leave exactly one line on stdout --
+    parseable, below the 6 KB limit, carrying `roofline` and (when the CPU leg ran) `cpu_baseline` -- and the full record in the
+    detail file.  Small workload: the numbers mean nothing, the plumbing is what is run."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        detail_path = os.path.join(tmp, "detail.json")
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2", "--scene-size", "256",
+               "--height", "96", "--width", "136", "--samples", "12", "--dropin-frames", "3", "--cpu-budget-s", "5"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
+                           env=dict(os.environ, SDN_BENCH_DETAIL=detail_path, SDN_CPU_THREADS="16"))
+        assert r.returncode == 0, r.stderr[-3000:]
+        full = json.load(open(detail_path))
+    assert r.stdout.endswith("\n") and r.stdout.count("\n") == 1 and len(r.stdout.encode()) < 6144, r.stdout[-1500:]
+    d = json.loads(r.stdout)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 2 and d["value"] > 0 and d["unit"] == "frames/s" and d["higher_is_better"] is True
+    assert abs(d["ms_per_step"] * d["value"] - 1000.0) < 1.0                              # one frame per step
+    roof = d["roofline"]
+    assert roof["bound"] == "mfma" and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and roof["avg_launch_ms"] > 0
+    assert d["cpu_baseline"]["kind"] in ("reference", "port") and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["precision"]["max_abs_err"] < d["precision"]["bound"] == 1e-3
+    for k in ("floor_frames_per_s", "colour_skip_off_frames_per_s", "style_setup_ms", "calibration_ms", "first_frame_ms", "trajectory40_frames_per_s"):
+        assert d[k] > 0, k
+    if "skipped" not in (full.get("dropin") or {}):
+        assert d["dropin_frames_per_s"] > 0
+        assert "Rendering frame" in r.stderr and "Rendering frame" not in r.stdout      # the reference loop's prints went to stderr
+    # the detail file is the full record: everything on the line is in it, plus what the line leaves out
+    assert full["value"] == pytest.approx(d["value"], rel=1e-4) and "gates" in full["precision"] and "timing" in full["roofline"]
+    assert (full["floor"]["passes_skipped_by_termination"], full["floor"]["colour_branch_skipped_fraction"]) == (0.0, 0.0)
